@@ -1,0 +1,734 @@
+// C ABI of the gfx950 visual front-end device layer (declared in include/ft_device.h).
+//
+// Owns the pyramid arena in HBM, the pinned staging buffers and one HIP queue per context; launches the
+// hand-written kernels in ft_kernels_*.hpp.  No torch types, no exceptions across the boundary.
+#include "ft_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ft_common.hpp"
+#include "ft_kernels_fast.hpp"
+#include "ft_kernels_lk.hpp"
+#include "ft_kernels_pyramid.hpp"
+
+using namespace ftd;
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct SlotState {
+    int w = 0, h = 0;
+    int levels = 0;        // images valid (0 = no frame)
+    int grad_levels = 0;   // gradient images valid
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind = 0;   // 0 pyramid, 1 lk, 2 fast
+};
+
+struct PendingLK {
+    bool active = false;
+    std::vector<ft_lk_job> jobs;
+    int total = 0;
+    int nlev = 0;
+    bool want_iters = false;
+};
+
+struct PendingFast {
+    bool active = false;
+    int n = 0, cells = 0, per_cell = 0, cap = 0;
+    ft_keypoint* out = nullptr;
+    int* n_out = nullptr;
+    int* cell_counts = nullptr;
+};
+
+}  // namespace
+
+struct ft_ctx {
+    int device = 0;
+    ft_limits lim{};
+    hipStream_t q = nullptr;
+    ArenaDesc arena{};
+    int lvl_w[FT_MAX_LEVELS]{}, lvl_h[FT_MAX_LEVELS]{};   // geometry of the largest frame
+    std::vector<SlotState> slots;
+
+    // frame upload staging: one pinned buffer per slot + completion event
+    uint8_t* stage = nullptr;
+    size_t stage_bytes_per_slot = 0;
+    std::vector<hipEvent_t> stage_done;
+    std::vector<char> stage_busy;
+
+    // LK staging
+    uint8_t* lk_in_host = nullptr;  uint8_t* lk_in_dev = nullptr;  size_t lk_in_bytes = 0;
+    uint8_t* lk_out_host = nullptr; uint8_t* lk_out_dev = nullptr; size_t lk_out_bytes = 0;
+    PendingLK lk_pending;
+
+    // FAST scratch
+    uint8_t* score = nullptr; uint32_t score_pitch = 0; uint64_t score_img_bytes = 0;
+    uint32_t* cand = nullptr; size_t cand_entries_per_img = 0;
+    int* cand_count = nullptr;          // [n_streams][max_grid_cells]
+    ft_keypoint* kp_dev = nullptr;      // [n_streams][max_grid_cells][max_per_cell]
+    int* kp_count_dev = nullptr;        // [n_streams][max_grid_cells]
+    uint8_t* fast_out_host = nullptr; size_t fast_out_bytes = 0;
+    PendingFast fast_pending;
+
+    // small device scratch for ft_predict_flow
+    float* pf_dev = nullptr; float* pf_host = nullptr; size_t pf_points = 0;
+
+    // timing
+    bool profile = false;
+    std::vector<EventPair> ev_inflight;
+    std::vector<EventPair> ev_pool;
+    ft_kernel_time times{};
+    hipEvent_t region_a = nullptr, region_b = nullptr;
+
+    std::string hip_err;
+};
+
+namespace {
+
+#define FT_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (ctx)->hip_err = std::string(#call) + ": " + hipGetErrorString(e__);                   \
+            return FT_E_HIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+int slot_index(const ft_ctx* c, int stream, int slot) {
+    if (stream < 0 || stream >= c->lim.n_streams || slot < 0 || slot >= c->lim.n_slots) return -1;
+    return stream * c->lim.n_slots + slot;
+}
+
+void prof_begin(ft_ctx* c, int kind, EventPair& ep) {
+    if (!c->profile) return;
+    if (!c->ev_pool.empty()) { ep = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
+    ep.kind = kind;
+    (void)hipEventRecord(ep.a, c->q);
+}
+void prof_end(ft_ctx* c, EventPair& ep) {
+    if (!c->profile || !ep.a) return;
+    (void)hipEventRecord(ep.b, c->q);
+    c->ev_inflight.push_back(ep);
+}
+void prof_collect(ft_ctx* c) {
+    for (auto& ep : c->ev_inflight) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            if (ep.kind == 0) { c->times.pyramid_ms += ms; c->times.pyramid_launches++; }
+            else if (ep.kind == 1) { c->times.lk_ms += ms; c->times.lk_launches++; }
+            else { c->times.fast_ms += ms; c->times.fast_launches++; }
+        }
+        c->ev_pool.push_back(ep);
+    }
+    c->ev_inflight.clear();
+}
+
+// number of the top level buildOpticalFlowPyramid would produce (early stop when the next level <= window)
+int achieved_level(int w, int h, int win_w, int win_h, int max_level) {
+    int level = 0;
+    for (; level <= max_level; level++) {
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win_w || h <= win_h) return level;
+    }
+    return max_level;
+}
+
+int deliver_pending(ft_ctx* c) {
+    // called after the queue has drained
+    if (c->lk_pending.active) {
+        PendingLK& P = c->lk_pending;
+        const size_t N = (size_t)P.total;
+        const float* xy = reinterpret_cast<const float*>(c->lk_out_host);
+        const float* er = reinterpret_cast<const float*>(c->lk_out_host + 8 * N);
+        const uint8_t* st = c->lk_out_host + 12 * N;
+        const int* it = reinterpret_cast<const int*>(c->lk_out_host + align_up(13 * N, 16));
+        size_t off = 0;
+        for (const ft_lk_job& j : P.jobs) {
+            const size_t n = (size_t)j.n;
+            if (n) {
+                memcpy(j.next_xy, xy + 2 * off, 8 * n);
+                memcpy(j.err, er + off, 4 * n);
+                memcpy(j.status, st + off, n);
+                if (j.iters && P.want_iters) memcpy(j.iters, it + off * P.nlev, sizeof(int) * n * P.nlev);
+            }
+            off += n;
+        }
+        P.active = false;
+    }
+    if (c->fast_pending.active) {
+        PendingFast& F = c->fast_pending;
+        const size_t per_img = (size_t)F.cells * F.per_cell;
+        const ft_keypoint* kp = reinterpret_cast<const ft_keypoint*>(c->fast_out_host);
+        const int* cnt = reinterpret_cast<const int*>(c->fast_out_host + align_up(sizeof(ft_keypoint) * per_img * F.n, 16));
+        const int* ccnt = cnt + (size_t)F.n * F.cells;
+        for (int i = 0; i < F.n; i++) {
+            int m = 0;
+            for (int cell = 0; cell < F.cells; cell++) {
+                const int k = cnt[(size_t)i * F.cells + cell];
+                const ft_keypoint* src = kp + (size_t)i * per_img + (size_t)cell * F.per_cell;
+                for (int r = 0; r < k && m < F.cap; r++) F.out[(size_t)i * F.cap + m++] = src[r];
+            }
+            if (F.n_out) F.n_out[i] = m;
+            if (F.cell_counts) memcpy(F.cell_counts + (size_t)i * F.cells, ccnt + (size_t)i * F.cells, sizeof(int) * F.cells);
+        }
+        F.active = false;
+    }
+    return FT_OK;
+}
+
+int sync_and_deliver(ft_ctx* c) {
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    std::fill(c->stage_busy.begin(), c->stage_busy.end(), 0);
+    prof_collect(c);
+    return deliver_pending(c);
+}
+
+int pick_seglen(int win_w, int win_h) {
+    const int opts[3] = {4, 8, 16};
+    for (int s : opts) {
+        const int segs = (win_w + s - 1) / s;
+        if (segs * win_h <= 64) return s;
+    }
+    return 0;
+}
+
+static int collect_images(ft_ctx* c, int n, const int* streams, const int* slots, ImgList& L, int& w, int& h) {
+    if (n < 1 || n > FT_MAX_BATCH || !streams || !slots) return FT_E_INVALID;
+    L.n = n;
+    for (int i = 0; i < n; i++) {
+        const int si = slot_index(c, streams[i], slots[i]);
+        if (si < 0) return FT_E_INVALID;
+        const SlotState& S = c->slots[si];
+        if (S.levels < 1) return FT_E_STATE;
+        if (i == 0) { w = S.w; h = S.h; }
+        else if (S.w != w || S.h != h) return FT_E_INVALID;
+        L.idx[i] = si;
+    }
+    return FT_OK;
+}
+
+static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool down, bool grad) {
+    EventPair ep;
+    prof_begin(c, 0, ep);
+    int lw = w, lh = h;
+    for (int l = 0; l <= top; l++) {
+        const int do_down = (down && l < top) ? 1 : 0;
+        const int do_grad = grad ? 1 : 0;
+        if (do_down || do_grad) {
+            dim3 grid((lw + LV_TX - 1) / LV_TX, (lh + LV_TY - 1) / LV_TY, L.n);
+            hipLaunchKernelGGL(level_kernel, grid, dim3(256), 0, c->q, c->arena, L, l, lw, lh, do_grad, do_down);
+        }
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+    }
+    prof_end(c, ep);
+    FT_HIP(c, hipGetLastError());
+    return FT_OK;
+}
+
+template <int SEGLEN>
+static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
+    hipLaunchKernelGGL((lk_kernel<SEGLEN>), dim3(total), dim3(64), 0, c->q, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ft_strerror(int code) {
+    switch (code) {
+        case FT_OK: return "ok";
+        case FT_E_INVALID: return "invalid argument";
+        case FT_E_LIMIT: return "exceeds context limits";
+        case FT_E_HIP: return "HIP runtime error";
+        case FT_E_NOMEM: return "out of memory";
+        case FT_E_STATE: return "slot has no frame, pyramid or gradients";
+        case FT_E_NODEVICE: return "no usable GPU device";
+        default: return "unknown error";
+    }
+}
+
+const char* ft_last_hip_error(ft_ctx* ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
+
+int ft_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
+    if (!out || !lim) return FT_E_INVALID;
+    *out = nullptr;
+    if (lim->max_width < 1 || lim->max_height < 1 || lim->max_levels < 1 || lim->max_levels > FT_MAX_LEVELS ||
+        lim->n_streams < 1 || lim->n_streams > FT_MAX_BATCH || lim->n_slots < 1 || lim->max_points < 1 ||
+        lim->max_grid_cells < 1 || lim->max_per_cell < 1)
+        return FT_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FT_E_NODEVICE;
+    ft_ctx* c = new (std::nothrow) ft_ctx();
+    if (!c) return FT_E_NOMEM;
+    c->device = device;
+    c->lim = *lim;
+    auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);
+    if (hipStreamCreateWithFlags(&c->q, hipStreamNonBlocking) != hipSuccess) return fail(FT_E_HIP);
+
+    // arena layout from the largest frame
+    size_t off = 0;
+    int w = lim->max_width, h = lim->max_height;
+    for (int l = 0; l < lim->max_levels; l++) {
+        c->lvl_w[l] = w; c->lvl_h[l] = h;
+        LevelDesc& d = c->arena.lv[l];
+        d.img_pitch = (uint32_t)align_up((size_t)w, 256);
+        d.grad_pitch = (uint32_t)align_up((size_t)w * 4, 256);
+        d.img_off = off; off += align_up((size_t)d.img_pitch * h, 256);
+        d.grad_off = off; off += align_up((size_t)d.grad_pitch * h, 256);
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    c->arena.slot_bytes = align_up(off, 4096);
+    const size_t n_slots_total = (size_t)lim->n_streams * lim->n_slots;
+    c->slots.resize(n_slots_total);
+    void* p = nullptr;
+    if (hipMalloc(&p, c->arena.slot_bytes * n_slots_total) != hipSuccess) return fail(FT_E_NOMEM);
+    c->arena.base = (uint8_t*)p;
+
+    c->stage_bytes_per_slot = align_up((size_t)lim->max_width * lim->max_height, 4096);
+    if (hipHostMalloc(&p, c->stage_bytes_per_slot * n_slots_total, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+    c->stage = (uint8_t*)p;
+    c->stage_done.resize(n_slots_total, nullptr);
+    c->stage_busy.assign(n_slots_total, 0);
+    for (auto& e : c->stage_done)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(FT_E_HIP);
+
+    // LK staging
+    const size_t N = (size_t)lim->max_points;
+    c->lk_in_bytes = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256) + align_up(2 * N, 256) + 2 * align_up(8 * N, 256);
+    c->lk_out_bytes = align_up(13 * N, 16) + sizeof(int) * N * FT_MAX_LEVELS + 256;
+    if (hipHostMalloc(&p, c->lk_in_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+    c->lk_in_host = (uint8_t*)p;
+    if (hipMalloc(&p, c->lk_in_bytes) != hipSuccess) return fail(FT_E_NOMEM);
+    c->lk_in_dev = (uint8_t*)p;
+    if (hipHostMalloc(&p, c->lk_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+    c->lk_out_host = (uint8_t*)p;
+    if (hipMalloc(&p, c->lk_out_bytes) != hipSuccess) return fail(FT_E_NOMEM);
+    c->lk_out_dev = (uint8_t*)p;
+
+    // FAST scratch
+    c->score_pitch = (uint32_t)align_up((size_t)lim->max_width, 256);
+    c->score_img_bytes = (uint64_t)c->score_pitch * lim->max_height;
+    if (hipMalloc(&p, c->score_img_bytes * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
+    c->score = (uint8_t*)p;
+    c->cand_entries_per_img = ((size_t)lim->max_width + 2 * 64) * ((size_t)lim->max_height + 2 * 64) / 4 + (size_t)lim->max_grid_cells;
+    if (hipMalloc(&p, sizeof(uint32_t) * c->cand_entries_per_img * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
+    c->cand = (uint32_t*)p;
+    const size_t cells_total = (size_t)lim->n_streams * lim->max_grid_cells;
+    if (hipMalloc(&p, sizeof(int) * cells_total * 2) != hipSuccess) return fail(FT_E_NOMEM);
+    c->cand_count = (int*)p;
+    c->kp_count_dev = c->cand_count + cells_total;
+    if (hipMalloc(&p, sizeof(ft_keypoint) * cells_total * lim->max_per_cell) != hipSuccess) return fail(FT_E_NOMEM);
+    c->kp_dev = (ft_keypoint*)p;
+    c->fast_out_bytes = align_up(sizeof(ft_keypoint) * cells_total * lim->max_per_cell, 16) + sizeof(int) * cells_total * 2 + 256;
+    if (hipHostMalloc(&p, c->fast_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+    c->fast_out_host = (uint8_t*)p;
+
+    c->pf_points = N;
+    if (hipMalloc(&p, sizeof(float) * (4 * N + 16)) != hipSuccess) return fail(FT_E_NOMEM);
+    c->pf_dev = (float*)p;
+    if (hipHostMalloc(&p, sizeof(float) * (4 * N + 16), hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+    c->pf_host = (float*)p;
+
+    if (hipEventCreate(&c->region_a) != hipSuccess || hipEventCreate(&c->region_b) != hipSuccess) return fail(FT_E_HIP);
+    *out = c;
+    return FT_OK;
+}
+
+void ft_ctx_destroy(ft_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->q) (void)hipStreamSynchronize(c->q);
+    for (auto& e : c->stage_done) if (e) (void)hipEventDestroy(e);
+    for (auto& ep : c->ev_inflight) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (c->region_a) (void)hipEventDestroy(c->region_a);
+    if (c->region_b) (void)hipEventDestroy(c->region_b);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->stage) (void)hipHostFree(c->stage);
+    if (c->lk_in_host) (void)hipHostFree(c->lk_in_host);
+    if (c->lk_in_dev) (void)hipFree(c->lk_in_dev);
+    if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
+    if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
+    if (c->score) (void)hipFree(c->score);
+    if (c->cand) (void)hipFree(c->cand);
+    if (c->cand_count) (void)hipFree(c->cand_count);
+    if (c->kp_dev) (void)hipFree(c->kp_dev);
+    if (c->fast_out_host) (void)hipHostFree(c->fast_out_host);
+    if (c->pf_dev) (void)hipFree(c->pf_dev);
+    if (c->pf_host) (void)hipHostFree(c->pf_host);
+    if (c->q) (void)hipStreamDestroy(c->q);
+    delete c;
+}
+
+int ft_upload(ft_ctx* c, int stream, int slot, const uint8_t* host, int w, int h, size_t stride) {
+    if (!c || !host || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    if (si < 0) return FT_E_INVALID;
+    if (w > c->lim.max_width || h > c->lim.max_height) return FT_E_LIMIT;
+    FT_HIP(c, hipSetDevice(c->device));
+    if (c->stage_busy[si]) {   // a previous upload from this staging buffer may still be in flight
+        FT_HIP(c, hipEventSynchronize(c->stage_done[si]));
+        c->stage_busy[si] = 0;
+    }
+    uint8_t* st = c->stage + (size_t)si * c->stage_bytes_per_slot;
+    for (int y = 0; y < h; y++) memcpy(st + (size_t)y * w, host + (size_t)y * stride, (size_t)w);
+    uint8_t* dst = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[0].img_off;
+    FT_HIP(c, hipMemcpy2DAsync(dst, c->arena.lv[0].img_pitch, st, (size_t)w, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->q));
+    FT_HIP(c, hipEventRecord(c->stage_done[si], c->q));
+    c->stage_busy[si] = 1;
+    c->slots[si] = SlotState{w, h, 1, 0};
+    return FT_OK;
+}
+
+int ft_set_frame_device(ft_ctx* c, int stream, int slot, const void* dev, int w, int h, size_t stride) {
+    if (!c || !dev || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    if (si < 0) return FT_E_INVALID;
+    if (w > c->lim.max_width || h > c->lim.max_height) return FT_E_LIMIT;
+    FT_HIP(c, hipSetDevice(c->device));
+    uint8_t* dst = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[0].img_off;
+    FT_HIP(c, hipMemcpy2DAsync(dst, c->arena.lv[0].img_pitch, dev, stride, (size_t)w, (size_t)h, hipMemcpyDeviceToDevice, c->q));
+    c->slots[si] = SlotState{w, h, 1, 0};
+    return FT_OK;
+}
+
+int ft_build_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
+                     int with_gradients, int* achieved) {
+    if (!c || max_level < 0 || win_w < 3 || win_h < 3) return FT_E_INVALID;
+    if (max_level + 1 > c->lim.max_levels) return FT_E_LIMIT;
+    ImgList L;
+    int w = 0, h = 0;
+    int rc = collect_images(c, n, streams, slots, L, w, h);
+    if (rc) return rc;
+    FT_HIP(c, hipSetDevice(c->device));
+    const int top = achieved_level(w, h, win_w, win_h, max_level);
+    rc = run_levels(c, L, w, h, top, true, with_gradients != 0);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        SlotState& S = c->slots[L.idx[i]];
+        S.levels = top + 1;
+        S.grad_levels = with_gradients ? top + 1 : 0;
+        if (achieved) achieved[i] = top;
+    }
+    return FT_OK;
+}
+
+int ft_build_gradients(ft_ctx* c, int n, const int* streams, const int* slots) {
+    if (!c) return FT_E_INVALID;
+    ImgList L;
+    int w = 0, h = 0;
+    int rc = collect_images(c, n, streams, slots, L, w, h);
+    if (rc) return rc;
+    int levels = c->slots[L.idx[0]].levels;
+    for (int i = 1; i < n; i++) if (c->slots[L.idx[i]].levels != levels) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    rc = run_levels(c, L, w, h, levels - 1, false, true);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) c->slots[L.idx[i]].grad_levels = levels;
+    return FT_OK;
+}
+
+int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) {
+    if (!c || !jobs || !prm || n_jobs < 1 || n_jobs > FT_MAX_BATCH) return FT_E_INVALID;
+    if (prm->win_w < 3 || prm->win_h < 3 || prm->win_w > FT_MAX_WIN || prm->win_h > FT_MAX_WIN || prm->max_level < 0) return FT_E_INVALID;
+    if (prm->max_level + 1 > FT_MAX_LEVELS) return FT_E_LIMIT;
+    const int seglen = pick_seglen(prm->win_w, prm->win_h);
+    if (!seglen) return FT_E_INVALID;
+    const bool fb = (prm->flags & FT_LK_FORWARD_BACKWARD) != 0;
+    FT_HIP(c, hipSetDevice(c->device));
+    if (c->lk_pending.active) {   // staging is single-buffered: finish the previous batch first
+        int rc = sync_and_deliver(c);
+        if (rc) return rc;
+    }
+
+    size_t total = 0;
+    bool want_iters = false;
+    for (int j = 0; j < n_jobs; j++) {
+        const ft_lk_job& J = jobs[j];
+        if (J.n < 0) return FT_E_INVALID;
+        if (J.n > 0 && (!J.prev_xy || !J.next_xy || !J.status || !J.err)) return FT_E_INVALID;
+        total += (size_t)J.n;
+        if (J.iters) want_iters = true;
+    }
+    if (total > (size_t)c->lim.max_points) return FT_E_LIMIT;
+    const int nlev = prm->max_level + 1;
+
+    // pack the input block
+    const size_t N = total;
+    uint8_t* hb = c->lk_in_host;
+    const size_t off_ptjob = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256);
+    const size_t off_prev = off_ptjob + align_up(2 * (size_t)c->lim.max_points, 256);
+    const size_t off_next = off_prev + align_up(8 * (size_t)c->lim.max_points, 256);
+    LKJobDev* dj = reinterpret_cast<LKJobDev*>(hb);
+    uint16_t* ptjob = reinterpret_cast<uint16_t*>(hb + off_ptjob);
+    float* pxy = reinterpret_cast<float*>(hb + off_prev);
+    float* nxy = reinterpret_cast<float*>(hb + off_next);
+    int max_level_all = -1;
+    size_t off = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const ft_lk_job& J = jobs[j];
+        const int sp = slot_index(c, J.stream_prev, J.slot_prev), sn = slot_index(c, J.stream_next, J.slot_next);
+        if (sp < 0 || sn < 0) return FT_E_INVALID;
+        const SlotState& P = c->slots[sp];
+        const SlotState& Q = c->slots[sn];
+        if (P.levels < 1 || Q.levels < 1) return FT_E_STATE;
+        if (P.w != Q.w || P.h != Q.h) return FT_E_INVALID;
+        const int ml = std::min(prm->max_level, std::min(P.levels, Q.levels) - 1);
+        if (P.grad_levels < ml + 1) return FT_E_STATE;
+        if (fb && Q.grad_levels < ml + 1) return FT_E_STATE;
+        if (max_level_all < 0) max_level_all = ml;
+        else if (ml != max_level_all) return FT_E_INVALID;   // one batch, one pyramid depth
+        dj[j].img_prev = sp; dj[j].img_next = sn; dj[j].w0 = P.w; dj[j].h0 = P.h;
+        dj[j].use_H = J.H ? 1 : 0;
+        if (J.H) memcpy(dj[j].H, J.H, sizeof(float) * 9); else memset(dj[j].H, 0, sizeof(float) * 9);
+        for (int i = 0; i < J.n; i++) ptjob[off + i] = (uint16_t)j;
+        if (J.n) {
+            memcpy(pxy + 2 * off, J.prev_xy, 8 * (size_t)J.n);
+            memcpy(nxy + 2 * off, J.next_xy, 8 * (size_t)J.n);
+        }
+        off += (size_t)J.n;
+    }
+    if (N == 0) return FT_OK;
+
+    // one H2D copy for the whole block (jobs .. end of next_xy in use)
+    FT_HIP(c, hipMemcpyAsync(c->lk_in_dev, hb, off_next + 8 * N, hipMemcpyHostToDevice, c->q));
+
+    LKArgs a;
+    a.A = c->arena;
+    a.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
+    a.pt_job = reinterpret_cast<const uint16_t*>(c->lk_in_dev + off_ptjob);
+    a.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);
+    // the output block doubles as the in/out next_xy array: seed it with the guesses
+    uint8_t* ob = c->lk_out_dev;
+    FT_HIP(c, hipMemcpyAsync(ob, c->lk_in_dev + off_next, 8 * N, hipMemcpyDeviceToDevice, c->q));
+    a.next_xy = reinterpret_cast<float*>(ob);
+    a.err = reinterpret_cast<float*>(ob + 8 * N);
+    a.status = ob + 12 * N;
+    a.iters = want_iters ? reinterpret_cast<int*>(ob + align_up(13 * N, 16)) : nullptr;
+    a.nlev = nlev;
+    a.win_w = prm->win_w; a.win_h = prm->win_h;
+    a.segs = (prm->win_w + seglen - 1) / seglen;
+    a.max_level = max_level_all;
+    a.max_iter = std::min(std::max(prm->max_iter, 0), 100);
+    a.flags = prm->flags;
+    a.backward = 0;
+    a.fb_thresh2 = prm->fb_thresh * prm->fb_thresh;
+    const double eps = std::min(std::max(prm->eps, 0.), 10.);
+    a.epsilon = eps * eps;
+    a.min_eig = prm->min_eig;
+    if (want_iters) FT_HIP(c, hipMemsetAsync(a.iters, 0xff, sizeof(int) * N * nlev, c->q));
+
+    EventPair ep;
+    prof_begin(c, 1, ep);
+    for (int pass = 0; pass < (fb ? 2 : 1); pass++) {
+        a.backward = pass;
+        if (pass == 1) a.iters = nullptr;
+        switch (seglen) {
+            case 4: launch_lk<4>(c, a, (int)N); break;
+            case 8: launch_lk<8>(c, a, (int)N); break;
+            default: launch_lk<16>(c, a, (int)N); break;
+        }
+    }
+    prof_end(c, ep);
+    FT_HIP(c, hipGetLastError());
+
+    const size_t out_bytes = align_up(13 * N, 16) + (want_iters ? sizeof(int) * N * nlev : 0);
+    FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, c->q));
+
+    PendingLK& P = c->lk_pending;
+    P.jobs.assign(jobs, jobs + n_jobs);
+    P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.active = true;
+    return FT_OK;
+}
+
+int ft_lk_track(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) {
+    int rc = ft_lk_track_async(c, n_jobs, jobs, prm);
+    if (rc) return rc;
+    return ft_sync(c);
+}
+
+int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
+                       int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts) {
+    if (!c || !out || cap < 0 || grid_x < 1 || grid_y < 1 || per_cell < 1) return FT_E_INVALID;
+    ImgList L;
+    int w = 0, h = 0;
+    int rc = collect_images(c, n, streams, slots, L, w, h);
+    if (rc) return rc;
+    if (n > c->lim.n_streams) return FT_E_LIMIT;
+    FastGrid G;
+    G.w = w; G.h = h;
+    G.size_x = w / grid_x; G.size_y = h / grid_y;                    // Grider_FAST.h:80-81
+    if (G.size_x < 1 || G.size_y < 1 || G.size_x > 4096 || G.size_y > 4096) return FT_E_INVALID;
+    G.ct_cols = w / G.size_x; G.ct_rows = h / G.size_y;              // Grider_FAST.h:91-92
+    const int cells = G.ct_cols * G.ct_rows;
+    if (cells > c->lim.max_grid_cells || per_cell > c->lim.max_per_cell) return FT_E_LIMIT;
+    G.threshold = std::min(std::max(threshold, 0), 255);
+    G.per_cell = per_cell;
+    // a strict 3x3 maximum leaves at most one survivor per 2x2 block of the cell
+    const size_t need = (size_t)((G.size_x + 1) / 2) * ((G.size_y + 1) / 2);
+    G.cand_cap = (int)std::min(need, c->cand_entries_per_img / (size_t)cells);
+    FT_HIP(c, hipSetDevice(c->device));
+    if (c->fast_pending.active) {
+        rc = sync_and_deliver(c);
+        if (rc) return rc;
+    }
+    FT_HIP(c, hipMemsetAsync(c->cand_count, 0, sizeof(int) * (size_t)n * cells, c->q));
+    EventPair ep;
+    prof_begin(c, 2, ep);
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n);
+    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, c->q, c->arena, L, G, c->score, c->score_pitch, c->score_img_bytes);
+    hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, c->q, G, c->score, c->score_pitch, c->score_img_bytes, c->cand, c->cand_count);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3(n * cells), dim3(256), 0, c->q, G, c->cand, c->cand_count, c->kp_dev, c->kp_count_dev);
+    prof_end(c, ep);
+    FT_HIP(c, hipGetLastError());
+    // note: cand is indexed [image*cells + cell][cand_cap], kp_dev [image*cells + cell][per_cell]
+    const size_t kp_bytes = sizeof(ft_keypoint) * (size_t)n * cells * per_cell;
+    uint8_t* hb = c->fast_out_host;
+    FT_HIP(c, hipMemcpyAsync(hb, c->kp_dev, kp_bytes, hipMemcpyDeviceToHost, c->q));
+    int* cnt_h = reinterpret_cast<int*>(hb + align_up(kp_bytes, 16));
+    FT_HIP(c, hipMemcpyAsync(cnt_h, c->kp_count_dev, sizeof(int) * (size_t)n * cells, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipMemcpyAsync(cnt_h + (size_t)n * cells, c->cand_count, sizeof(int) * (size_t)n * cells, hipMemcpyDeviceToHost, c->q));
+    PendingFast& F = c->fast_pending;
+    F.active = true; F.n = n; F.cells = cells; F.per_cell = per_cell; F.cap = cap;
+    F.out = out; F.n_out = n_out; F.cell_counts = cell_counts;
+    return FT_OK;
+}
+
+int ft_fast_grid(ft_ctx* c, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
+                 int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts) {
+    int rc = ft_fast_grid_async(c, n, streams, slots, threshold, grid_x, grid_y, per_cell, out, cap, n_out, cell_counts);
+    if (rc) return rc;
+    return ft_sync(c);
+}
+
+void ft_homography(const float* K4, const float* R, float* H) {
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    const float ifx = 1.f / fx, ify = 1.f / fy, ncx = -cx / fx, ncy = -cy / fy;
+    float M[9];   // R * K^-1
+    for (int r = 0; r < 3; r++) {
+        M[3 * r] = R[3 * r] * ifx;
+        M[3 * r + 1] = R[3 * r + 1] * ify;
+        M[3 * r + 2] = R[3 * r] * ncx + R[3 * r + 1] * ncy + R[3 * r + 2];
+    }
+    for (int col = 0; col < 3; col++) {   // K * M
+        H[col] = fx * M[col] + cx * M[6 + col];
+        H[3 + col] = fy * M[3 + col] + cy * M[6 + col];
+        H[6 + col] = M[6 + col];
+    }
+}
+
+int ft_predict_flow(ft_ctx* c, const float* H, const float* xy, float* xy_out, int n) {
+    if (!c || !H || !xy || !xy_out || n < 0) return FT_E_INVALID;
+    if ((size_t)n > c->pf_points) return FT_E_LIMIT;
+    if (n == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    memcpy(c->pf_host, H, sizeof(float) * 9);
+    memcpy(c->pf_host + 16, xy, sizeof(float) * 2 * (size_t)n);
+    FT_HIP(c, hipMemcpyAsync(c->pf_dev, c->pf_host, sizeof(float) * (16 + 2 * (size_t)n), hipMemcpyHostToDevice, c->q));
+    float* out_dev = c->pf_dev + 16 + 2 * c->pf_points;
+    hipLaunchKernelGGL(predict_flow_kernel, dim3((n + 255) / 256), dim3(256), 0, c->q, c->pf_dev, c->pf_dev + 16, out_dev, n);
+    FT_HIP(c, hipGetLastError());
+    float* out_host = c->pf_host + 16 + 2 * c->pf_points;
+    FT_HIP(c, hipMemcpyAsync(out_host, out_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    memcpy(xy_out, out_host, sizeof(float) * 2 * (size_t)n);
+    return FT_OK;
+}
+
+int ft_level_info(ft_ctx* c, int stream, int slot, int level, int* w, int* h) {
+    if (!c) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    if (si < 0 || level < 0) return FT_E_INVALID;
+    const SlotState& S = c->slots[si];
+    if (level >= S.levels) return FT_E_STATE;
+    int lw = S.w, lh = S.h;
+    for (int l = 0; l < level; l++) { lw = (lw + 1) / 2; lh = (lh + 1) / 2; }
+    if (w) *w = lw;
+    if (h) *h = lh;
+    return FT_OK;
+}
+
+int ft_download_level(ft_ctx* c, int stream, int slot, int level, uint8_t* host, size_t stride) {
+    int w = 0, h = 0;
+    int rc = ft_level_info(c, stream, slot, level, &w, &h);
+    if (rc) return rc;
+    if (!host || stride < (size_t)w) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    FT_HIP(c, hipSetDevice(c->device));
+    const uint8_t* src = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[level].img_off;
+    FT_HIP(c, hipMemcpy2DAsync(host, stride, src, c->arena.lv[level].img_pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    return FT_OK;
+}
+
+int ft_download_grad(ft_ctx* c, int stream, int slot, int level, int16_t* host, size_t stride_shorts) {
+    int w = 0, h = 0;
+    int rc = ft_level_info(c, stream, slot, level, &w, &h);
+    if (rc) return rc;
+    if (!host || stride_shorts < 2 * (size_t)w) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    if (level >= c->slots[si].grad_levels) return FT_E_STATE;
+    FT_HIP(c, hipSetDevice(c->device));
+    const uint8_t* src = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[level].grad_off;
+    FT_HIP(c, hipMemcpy2DAsync(host, stride_shorts * 2, src, c->arena.lv[level].grad_pitch, (size_t)w * 4, (size_t)h, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    return FT_OK;
+}
+
+int ft_sync(ft_ctx* c) {
+    if (!c) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    return sync_and_deliver(c);
+}
+
+int ft_profile(ft_ctx* c, int enable) {
+    if (!c) return FT_E_INVALID;
+    c->profile = enable != 0;
+    return FT_OK;
+}
+
+int ft_kernel_times(ft_ctx* c, ft_kernel_time* out, int reset) {
+    if (!c || !out) return FT_E_INVALID;
+    int rc = ft_sync(c);
+    if (rc) return rc;
+    *out = c->times;
+    if (reset) c->times = ft_kernel_time{};
+    return FT_OK;
+}
+
+int ft_queue_time_begin(ft_ctx* c) {
+    if (!c) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    FT_HIP(c, hipEventRecord(c->region_a, c->q));
+    return FT_OK;
+}
+
+int ft_queue_time_end(ft_ctx* c, float* ms) {
+    if (!c || !ms) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    FT_HIP(c, hipEventRecord(c->region_b, c->q));
+    FT_HIP(c, hipEventSynchronize(c->region_b));
+    FT_HIP(c, hipEventElapsedTime(ms, c->region_a, c->region_b));
+    return FT_OK;
+}
+
+}  // extern "C"

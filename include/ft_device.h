@@ -1,0 +1,151 @@
+/*
+ * ft_device.h — C ABI of the MI355X (gfx950) visual front-end device layer.
+ *
+ * This is the boundary the reference would bind in place of its three OpenCV entry points and cv::FAST:
+ *   cv::buildOpticalFlowPyramid   src/track/TrackKLT.cpp:51-56      -> ft_build_pyramid
+ *   calcSharrDeriv (inside LK)    src/track/TrackKLT.cpp:306,:402   -> ft_build_pyramid(with_gradients) / ft_build_gradients
+ *   cv::calcOpticalFlowPyrLK      src/track/TrackKLT.cpp:306,:402   -> ft_lk_track
+ *   cv::FAST + sort + top-k       src/track/Grider_FAST.h:94-130    -> ft_fast_grid
+ *   K*R*K^-1 point warp           src/track/TrackMsckfVio.cpp:348-355 (commented sketch) -> ft_lk_job::H / ft_predict_flow
+ *
+ * Conventions
+ *  - A context owns ALL device memory (a ring of `n_slots` pyramids + gradient pyramids for each of `n_streams`
+ *    independent camera streams), the pinned staging buffers and one HIP queue.  Host pointers are borrowed for the
+ *    duration of a call only, except the outputs of the *_async calls, which are written by the next ft_sync.
+ *  - Every compute entry point is batched: it takes arrays of (stream, slot) pairs and covers all of them in one
+ *    launch per kernel.  All images of one batched call must have the same size.
+ *  - Calls on one context must be serialised by the caller (same contract as the reference's per-camera mutex,
+ *    src/track/TrackBase.h:59-66).  Different contexts may be driven from different host threads.
+ *  - All functions return 0 (FT_OK) or a negative FT_E_* code; nothing throws or exits.
+ */
+#ifndef FT_DEVICE_H
+#define FT_DEVICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FT_OK 0
+#define FT_E_INVALID (-1)   /* bad argument */
+#define FT_E_LIMIT (-2)     /* exceeds the limits the context was created with */
+#define FT_E_HIP (-3)       /* a HIP runtime call failed; see ft_last_hip_error */
+#define FT_E_NOMEM (-4)     /* allocation failed */
+#define FT_E_STATE (-5)     /* slot has no frame / pyramid / gradients yet */
+#define FT_E_NODEVICE (-6)  /* no usable gfx950 device */
+
+#define FT_MAX_LEVELS 8     /* images per pyramid (max_level + 1) */
+#define FT_MAX_WIN 32       /* largest LK window side */
+#define FT_MAX_BATCH 256    /* images or LK jobs per batched call */
+
+/* LK flags; the first two keep OpenCV's OPTFLOW_* values so call sites read the same */
+#define FT_LK_USE_INITIAL_FLOW 4
+#define FT_LK_GET_MIN_EIGENVALS 8
+#define FT_LK_FORWARD_BACKWARD 256
+
+typedef struct ft_ctx ft_ctx;
+
+typedef struct ft_limits {
+    int max_width, max_height;   /* largest frame */
+    int max_levels;              /* images per pyramid, 1..FT_MAX_LEVELS */
+    int n_streams;               /* independent camera streams held by this context */
+    int n_slots;                 /* pyramid ring depth per stream (>= 2 for frame-to-frame tracking) */
+    int max_points;              /* total LK points per batched call */
+    int max_grid_cells;          /* grid_x*grid_y upper bound for ft_fast_grid */
+    int max_per_cell;            /* per-cell keep count upper bound for ft_fast_grid */
+} ft_limits;
+
+typedef struct ft_lk_params {
+    int win_w, win_h;    /* reference: 15x15, src/track/TrackKLT.h:122 */
+    int max_level;       /* reference: 3,    src/track/TrackKLT.h:121 */
+    int max_iter;        /* reference: 15,   src/track/TrackKLT.cpp:305,:401 */
+    double eps;          /* reference: 0.01 */
+    double min_eig;      /* OpenCV default 1e-4 */
+    int flags;           /* FT_LK_* */
+    float fb_thresh;     /* px; only with FT_LK_FORWARD_BACKWARD */
+} ft_lk_params;
+
+/* One LK job = one calcOpticalFlowPyrLK call of the reference (one image pair, n points). */
+typedef struct ft_lk_job {
+    int stream_prev, slot_prev;   /* template pyramid; needs gradients */
+    int stream_next, slot_next;   /* target pyramid (needs gradients too when FT_LK_FORWARD_BACKWARD is set) */
+    int n;                        /* number of points */
+    const float* prev_xy;         /* n*2, level-0 pixels */
+    float* next_xy;               /* n*2, in: initial guess (FT_LK_USE_INITIAL_FLOW and H == NULL), out: result */
+    uint8_t* status;              /* n */
+    float* err;                   /* n */
+    const float* H;               /* optional row-major 3x3: the initial guess becomes pi(H*[prev;1]) (gyro seed) */
+    int* iters;                   /* optional n*(max_level+1): Newton iterations per level, -1 = level skipped */
+} ft_lk_job;
+
+typedef struct ft_keypoint {
+    float x, y;          /* full-image pixel position */
+    float response;      /* FAST score */
+} ft_keypoint;
+
+/* Per-kernel device time accumulated while ft_profile(ctx, 1) is on (HIP events on the context's queue). */
+typedef struct ft_kernel_time {
+    double pyramid_ms;   int pyramid_launches;    /* fused pyrDown + Scharr level kernel */
+    double lk_ms;        int lk_launches;
+    double fast_ms;      int fast_launches;       /* score + nms/compact + top-k, per ft_fast_grid call */
+} ft_kernel_time;
+
+int ft_ctx_create(ft_ctx** out, int device, const ft_limits* limits);
+void ft_ctx_destroy(ft_ctx* ctx);
+
+/* Frame ingest.  ft_upload copies the host image into pinned staging (so the caller may reuse its buffer at
+ * once, as after the clone() at src/track/TrackKLT.cpp:46-47) and enqueues the H2D copy into level 0.
+ * ft_set_frame_device enqueues a device-to-device copy from a frame already resident in HBM. */
+int ft_upload(ft_ctx* ctx, int stream, int slot, const uint8_t* host, int w, int h, size_t stride);
+int ft_set_frame_device(ft_ctx* ctx, int stream, int slot, const void* dev, int w, int h, size_t stride);
+
+/* Levels 1..max_level by pyrDown and, if with_gradients, Scharr (Ix,Iy) of every level, for n images in one
+ * launch per level.  achieved[i] (optional) receives the top level index after the early-stop rule of
+ * buildOpticalFlowPyramid (stop when the next level would not exceed the window). Asynchronous. */
+int ft_build_pyramid(ft_ctx* ctx, int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
+                     int with_gradients, int* achieved);
+/* Scharr gradients for pyramids that were built without them. Asynchronous. */
+int ft_build_gradients(ft_ctx* ctx, int n, const int* streams, const int* slots);
+
+/* Pyramidal LK for n_jobs image pairs in one launch.  ft_lk_track returns with the outputs written;
+ * ft_lk_track_async returns after enqueueing and the outputs are written by the next ft_sync. */
+int ft_lk_track(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm);
+int ft_lk_track_async(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm);
+
+/* Per-cell FAST-9/16 + 3x3 NMS + per-cell top `per_cell` by (response desc, y asc, x asc), for n images.
+ * Image i writes at most `cap` keypoints at out + i*cap, cells in index order, and its count to n_out[i].
+ * cell_counts (optional, n*cells) receives the number of NMS survivors per cell before truncation. */
+int ft_fast_grid(ft_ctx* ctx, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
+                 int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts);
+int ft_fast_grid_async(ft_ctx* ctx, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
+                       int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts);
+
+/* H = K*R*K^-1 (host, float32; K4 = fx,fy,cx,cy) and the device point warp p' = pi(H*[p;1]). */
+void ft_homography(const float* K4, const float* R_p_c, float* H);
+int ft_predict_flow(ft_ctx* ctx, const float* H, const float* xy, float* xy_out, int n);
+
+/* Parity/debug readback. Synchronous. */
+int ft_level_info(ft_ctx* ctx, int stream, int slot, int level, int* w, int* h);
+int ft_download_level(ft_ctx* ctx, int stream, int slot, int level, uint8_t* host, size_t stride);
+int ft_download_grad(ft_ctx* ctx, int stream, int slot, int level, int16_t* host, size_t stride_shorts);
+
+/* Wait for everything enqueued on the context and deliver pending *_async outputs. */
+int ft_sync(ft_ctx* ctx);
+
+/* Timing. ft_profile(1) brackets every kernel group with HIP events on the context's queue (adds a little
+ * overhead); ft_kernel_times reads and optionally resets the totals.  ft_queue_time_* time a whole region. */
+int ft_profile(ft_ctx* ctx, int enable);
+int ft_kernel_times(ft_ctx* ctx, ft_kernel_time* out, int reset);
+int ft_queue_time_begin(ft_ctx* ctx);
+int ft_queue_time_end(ft_ctx* ctx, float* ms);
+
+const char* ft_strerror(int code);
+const char* ft_last_hip_error(ft_ctx* ctx);
+int ft_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+/*
+ * ft_oracle.h — C interface of the CPU parity oracle (TEST INFRASTRUCTURE, not product code).
+ *
+ * PARITY UNPINNED: the arithmetic restated here lives in OpenCV 3 (cv::buildOpticalFlowPyramid,
+ * cv::calcOpticalFlowPyrLK, cv::FAST), which the reference links but does not vendor, and the reference ships
+ * no test, fixture or golden vector for it.  This file restates the published algorithm of the generic
+ * (non-IPP, non-OpenCL) x86 code path; it is anchored on the reference's call sites only:
+ *   src/track/TrackKLT.cpp:51-56   (pyramid), :306 and :402 (pyramidal LK)
+ *   src/track/Grider_FAST.h:76-132 (per-cell FAST + top-k)
+ *   src/propagator/TrackPropagator.h:107-153 and src/track/TrackMsckfVio.cpp:344-355 (gyro seed)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#ifndef FT_ORACLE_H
+#define FT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flag values follow OpenCV's OPTFLOW_* enum so the call sites read the same */
+#define FTO_LK_USE_INITIAL_FLOW 4
+#define FTO_LK_GET_MIN_EIGENVALS 8
+#define FTO_LK_FORWARD_BACKWARD 256 /* build-defined: see fto_lk_track */
+
+typedef struct fto_pyramid fto_pyramid;
+
+typedef struct fto_lk_params {
+    int win_w, win_h;   /* TrackKLT.h:122 -> 15x15 */
+    int max_level;      /* TrackKLT.h:121 -> 3 */
+    int max_iter;       /* TermCriteria COUNT, TrackKLT.cpp:305,:401 -> 15 */
+    double eps;         /* TermCriteria EPS -> 0.01 (squared internally) */
+    double min_eig;     /* calcOpticalFlowPyrLK default 1e-4 */
+    int flags;          /* FTO_LK_* */
+    float fb_thresh;    /* forward-backward distance bound in px (only with FTO_LK_FORWARD_BACKWARD) */
+} fto_lk_params;
+
+typedef struct fto_keypoint {
+    float x, y;         /* pixel position (integers stored as float, like cv::KeyPoint::pt) */
+    float response;     /* FAST score */
+} fto_keypoint;
+
+/* cv::pyrDown for 8-bit single channel, BORDER_REFLECT_101. dst is ((w+1)/2) x ((h+1)/2). */
+void fto_pyr_down(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+
+/* cv::buildOpticalFlowPyramid(img, pyr, win, max_level, false, REFLECT_101, CONSTANT, true); TrackKLT.cpp:51-56.
+ * Returns a pyramid whose level count is (achieved max level + 1). */
+fto_pyramid* fto_pyramid_build(const uint8_t* img, int w, int h, size_t stride, int win_w, int win_h, int max_level);
+void fto_pyramid_free(fto_pyramid* p);
+int fto_pyramid_levels(const fto_pyramid* p);
+/* geometry + pointer to pixel (0,0) of a level; pixels at [-win, size+win) are valid (REFLECT_101 padding) */
+int fto_pyramid_level(const fto_pyramid* p, int level, int* w, int* h, size_t* stride, const uint8_t** data);
+
+/* calcSharrDeriv: dst holds w*h interleaved (Ix,Iy) int16 pairs, row stride = 2*w shorts. */
+void fto_scharr(const uint8_t* src, int w, int h, size_t sstride, int16_t* dst);
+
+/* cv::calcOpticalFlowPyrLK on two pyramids built without derivatives.
+ * next_xy is in/out (initial guess when FTO_LK_USE_INITIAL_FLOW is set).
+ * With FTO_LK_FORWARD_BACKWARD a second pass tracks next->prev seeded with the original point and clears status
+ * where that pass failed or lands farther than fb_thresh from the original point.
+ * iters_out (optional, n*(levels) ints, level-major per point: iters_out[i*nlev + level]) receives the number of
+ * Newton iterations executed per level (-1 where the level was skipped).
+ * n_threads <= 1 runs serially; otherwise features are split across std::threads. */
+int fto_lk_track(const fto_pyramid* prev, const fto_pyramid* next, const float* prev_xy, float* next_xy,
+                 uint8_t* status, float* err, int n, const fto_lk_params* prm, int n_threads, int* iters_out);
+
+/* cv::FAST(img, kps, threshold, nonmax) (FAST-9/16). Writes up to cap keypoints in row-major order, returns the
+ * total number found (may exceed cap). */
+int fto_fast(const uint8_t* img, int w, int h, size_t stride, int threshold, int nonmax, fto_keypoint* out, int cap);
+
+/* FAST score map used by the detector tests: score (0 where not a corner) for every pixel of the view. */
+void fto_fast_score_map(const uint8_t* img, int w, int h, size_t stride, int threshold, uint8_t* score, size_t sc_stride);
+
+/* Grider_FAST::perform_griding (Grider_FAST.h:76-132).
+ * tie_mode 0: per-cell order = (response desc, y asc, x asc)  — the total order this build defines.
+ * tie_mode 1: per-cell order = std::sort with the reference's comparator (libstdc++ introsort; unstable on ties).
+ * Returns number of keypoints written (<= cap). */
+int fto_grid_fast(const uint8_t* img, int w, int h, size_t stride, int num_features, int grid_x, int grid_y,
+                  int threshold, int nonmax, int tie_mode, int n_threads, fto_keypoint* out, int cap);
+
+/* Mean-gyro rotation between two frames (TrackPropagator.h:107-153 with the window end fixed to use the
+ * sample under the end iterator): R_p_c = Rodrigues(R_cam_imu_T * mean_gyro * dt)^T, row-major float[9].
+ * imu_t: n timestamps; gyro: n*3; R_imu_to_cam: row-major 3x3 (the rotation block of T_cam_imu). */
+int fto_integrate_gyro(const double* imu_t, const double* gyro, int n, double t_last, double t_cur,
+                       const double* R_imu_to_cam, float* R_p_c);
+
+/* p' = pi(K * R_p_c * K^-1 * [p;1]) in float32 (TrackMsckfVio.cpp:348-355). K = fx,fy,cx,cy. */
+void fto_predict_flow(const float* K4, const float* R_p_c, const float* xy, float* xy_out, int n);
+
+/* H = K * R * K^-1 as used by fto_predict_flow, row-major float[9]. */
+void fto_homography(const float* K4, const float* R_p_c, float* H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,177 @@
+"""ctypes binding of oracle/libft_oracle.so — the CPU parity oracle (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libft_oracle.so")
+
+LK_USE_INITIAL_FLOW = 4
+LK_GET_MIN_EIGENVALS = 8
+LK_FORWARD_BACKWARD = 256
+
+
+class fto_lk_params(C.Structure):
+    _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("max_iter", C.c_int),
+                ("eps", C.c_double), ("min_eig", C.c_double), ("flags", C.c_int), ("fb_thresh", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(ORACLE_DIR, "ft_oracle.cpp")
+    if not os.path.exists(LIB) or (os.path.exists(src) and os.path.getmtime(LIB) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    L = C.CDLL(LIB)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.fto_pyr_down.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
+    L.fto_pyr_down.restype = None
+    L.fto_pyramid_build.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    L.fto_pyramid_build.restype = vp
+    L.fto_pyramid_free.argtypes = [vp]
+    L.fto_pyramid_free.restype = None
+    L.fto_pyramid_levels.argtypes = [vp]
+    L.fto_pyramid_level.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_size_t), C.POINTER(vp)]
+    L.fto_scharr.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp]
+    L.fto_scharr.restype = None
+    L.fto_lk_track.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(fto_lk_params), C.c_int, vp]
+    L.fto_fast.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, C.c_int]
+    L.fto_fast_score_map.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_size_t]
+    L.fto_fast_score_map.restype = None
+    L.fto_grid_fast.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.fto_integrate_gyro.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, vp]
+    L.fto_predict_flow.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.fto_predict_flow.restype = None
+    L.fto_homography.argtypes = [vp, vp, vp]
+    L.fto_homography.restype = None
+    _lib = L
+    return L
+
+
+def _u8(img):
+    return np.ascontiguousarray(img, dtype=np.uint8)
+
+
+def pyr_down(img):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), dtype=np.uint8)
+    lib().fto_pyr_down(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, out.strides[0])
+    return out
+
+
+class Pyramid:
+    def __init__(self, img, win=15, max_level=3):
+        img = _u8(img)
+        h, w = img.shape
+        self.win = (win, win) if np.isscalar(win) else tuple(win)
+        self._p = lib().fto_pyramid_build(img.ctypes.data, w, h, img.strides[0], self.win[0], self.win[1], max_level)
+        if not self._p:
+            raise ValueError("fto_pyramid_build failed")
+
+    @property
+    def levels(self):
+        return lib().fto_pyramid_levels(self._p)
+
+    def level(self, l, with_border=False):
+        w, h, st, data = C.c_int(), C.c_int(), C.c_size_t(), C.c_void_p()
+        rc = lib().fto_pyramid_level(self._p, l, C.byref(w), C.byref(h), C.byref(st), C.byref(data))
+        if rc != 0:
+            raise IndexError(l)
+        bw, bh = (self.win if with_border else (0, 0))
+        base = data.value - bh * st.value - bw
+        rows = h.value + 2 * bh
+        buf = (C.c_uint8 * (rows * st.value)).from_address(base)
+        arr = np.frombuffer(buf, dtype=np.uint8).reshape(rows, st.value)[:, : w.value + 2 * bw]
+        return arr.copy()
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().fto_pyramid_free(self._p)
+            self._p = None
+
+
+def scharr(img):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((h, w, 2), dtype=np.int16)
+    lib().fto_scharr(img.ctypes.data, w, h, img.strides[0], out.ctypes.data)
+    return out
+
+
+def lk_track(prev, nxt, prev_xy, guess=None, win=15, max_level=3, max_iter=15, eps=0.01, min_eig=1e-4,
+             flags=LK_USE_INITIAL_FLOW, fb_thresh=1.0, n_threads=1, want_iters=False):
+    prev_xy = np.ascontiguousarray(prev_xy, dtype=np.float32).reshape(-1, 2)
+    n = prev_xy.shape[0]
+    out = np.array(prev_xy if guess is None else guess, dtype=np.float32).reshape(-1, 2).copy()
+    st = np.zeros(n, dtype=np.uint8)
+    er = np.zeros(n, dtype=np.float32)
+    win_w, win_h = (win, win) if np.isscalar(win) else win
+    p = fto_lk_params(win_w, win_h, max_level, max_iter, eps, min_eig, flags, fb_thresh)
+    nlev = min(max_level, prev.levels - 1) + 1
+    it = np.full((n, nlev), -1, dtype=np.int32) if want_iters else None
+    rc = lib().fto_lk_track(prev._p, nxt._p, prev_xy.ctypes.data, out.ctypes.data, st.ctypes.data, er.ctypes.data, n,
+                            C.byref(p), n_threads, None if it is None else it.ctypes.data)
+    if rc < 0:
+        raise RuntimeError(f"fto_lk_track rc={rc}")
+    return (out, st, er, it) if want_iters else (out, st, er)
+
+
+def fast(img, threshold=20, nonmax=True, cap=1 << 20):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((cap, 3), dtype=np.float32)
+    n = lib().fto_fast(img.ctypes.data, w, h, img.strides[0], threshold, int(nonmax), out.ctypes.data, cap)
+    return out[: min(n, cap)].copy()
+
+
+def fast_score_map(img, threshold=20):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((h, w), dtype=np.uint8)
+    lib().fto_fast_score_map(img.ctypes.data, w, h, img.strides[0], threshold, out.ctypes.data, out.strides[0])
+    return out
+
+
+def grid_fast(img, num_features, grid_x=5, grid_y=5, threshold=20, nonmax=True, tie_mode=0, n_threads=1, cap=1 << 18):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((cap, 3), dtype=np.float32)
+    n = lib().fto_grid_fast(img.ctypes.data, w, h, img.strides[0], num_features, grid_x, grid_y, threshold, int(nonmax),
+                            tie_mode, n_threads, out.ctypes.data, cap)
+    if n < 0:
+        raise ValueError("fto_grid_fast failed")
+    return out[:n].copy()
+
+
+def integrate_gyro(imu_t, gyro, t_last, t_cur, R_imu_to_cam):
+    imu_t = np.ascontiguousarray(imu_t, dtype=np.float64)
+    gyro = np.ascontiguousarray(gyro, dtype=np.float64).reshape(-1, 3)
+    R = np.ascontiguousarray(R_imu_to_cam, dtype=np.float64).reshape(9)
+    out = np.zeros(9, dtype=np.float32)
+    used = lib().fto_integrate_gyro(imu_t.ctypes.data, gyro.ctypes.data, len(imu_t), t_last, t_cur, R.ctypes.data, out.ctypes.data)
+    return out.reshape(3, 3), used
+
+
+def homography(K4, R):
+    K4 = np.ascontiguousarray(K4, dtype=np.float32)
+    R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+    H = np.zeros(9, dtype=np.float32)
+    lib().fto_homography(K4.ctypes.data, R.ctypes.data, H.ctypes.data)
+    return H.reshape(3, 3)
+
+
+def predict_flow(K4, R, xy):
+    K4 = np.ascontiguousarray(K4, dtype=np.float32)
+    R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    lib().fto_predict_flow(K4.ctypes.data, R.ctypes.data, xy.ctypes.data, out.ctypes.data, xy.shape[0])
+    return out

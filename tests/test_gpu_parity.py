@@ -1,0 +1,221 @@
+"""GPU parity: the gfx950 kernels, called through the C ABI (include/ft_device.h), against the CPU oracle.
+
+Bars: pyramids, gradients and FAST/grid selections bit-exact; LK positions within 0.01 px and status flags
+agreeing on >= 99.9 % of features (the kernels sum exactly like the oracle, so in practice they are identical).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 0.01        # px, tolerance stated by the north star
+STATUS_AGREE = 0.999
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from feature_tracker_amd import device as D
+    return D
+
+
+def _ctx(D, w, h, **kw):
+    args = dict(max_levels=6, n_streams=2, n_slots=2, max_points=20000, max_grid_cells=400, max_per_cell=32)
+    args.update(kw)
+    return D.DeviceContext(w, h, **args)
+
+
+@pytest.mark.parametrize("shape,win,max_level", [((480, 752), 21, 3), ((480, 752), 15, 3), ((720, 1280), 21, 4),
+                                                  ((479, 751), 15, 3), ((33, 47), 5, 2), ((100, 80), 21, 5),
+                                                  ((257, 129), 9, 4), ((8, 300), 3, 1)])
+def test_pyramid_and_gradients_bit_exact(dev, shape, win, max_level):
+    h, w = shape
+    img = synth.texture(w, h, seed=21) if min(shape) > 16 else np.random.default_rng(3).integers(0, 256, shape, dtype=np.uint8)
+    ref = O.Pyramid(img, win, max_level)
+    with _ctx(dev, w, h) as ctx:
+        ctx.upload(0, 0, img)
+        ach = ctx.build_pyramid([0], [0], max_level, win, with_gradients=True)
+        assert ach[0] == ref.levels - 1
+        for l in range(ref.levels):
+            assert np.array_equal(ctx.download_level(0, 0, l), ref.level(l)), f"level {l}"
+            assert np.array_equal(ctx.download_grad(0, 0, l), O.scharr(ref.level(l))), f"gradient {l}"
+
+
+def test_pyramid_random_noise_and_extremes(dev):
+    rng = np.random.default_rng(5)
+    for img in (rng.integers(0, 256, (240, 376), dtype=np.uint8), np.zeros((64, 200), np.uint8), np.full((64, 200), 255, np.uint8)):
+        h, w = img.shape
+        ref = O.Pyramid(img, 15, 2)
+        with _ctx(dev, w, h) as ctx:
+            ctx.upload(0, 0, img)
+            ctx.build_pyramid([0], [0], 2, 15, with_gradients=False)
+            ctx.build_gradients([0], [0])
+            for l in range(ref.levels):
+                assert np.array_equal(ctx.download_level(0, 0, l), ref.level(l))
+                assert np.array_equal(ctx.download_grad(0, 0, l), O.scharr(ref.level(l)))
+
+
+def test_pyramid_batched_streams(dev):
+    imgs = [synth.texture(376, 240, seed=30 + i) for i in range(4)]
+    with _ctx(dev, 376, 240, n_streams=4) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload(i, 1, im)
+        ctx.build_pyramid([0, 1, 2, 3], [1, 1, 1, 1], 3, 15)
+        for i, im in enumerate(imgs):
+            ref = O.Pyramid(im, 15, 3)
+            for l in range(ref.levels):
+                assert np.array_equal(ctx.download_level(i, 1, l), ref.level(l))
+                assert np.array_equal(ctx.download_grad(i, 1, l), O.scharr(ref.level(l)))
+
+
+def _compare_lk(gpu, ref, min_agree=STATUS_AGREE):
+    g_xy, g_st, g_err = gpu[:3]
+    r_xy, r_st, r_err = ref[:3]
+    agree = (g_st == r_st).mean()
+    assert agree >= min_agree, f"status agreement {agree}"
+    both = (g_st == 1) & (r_st == 1)
+    if both.any():
+        d = np.abs(g_xy[both] - r_xy[both]).max()
+        assert d <= POS_TOL, f"max position difference {d}"
+        assert np.abs(g_err[both] - r_err[both]).max() <= 1e-3
+    return agree
+
+
+@pytest.mark.parametrize("win,max_level,shape,n", [(21, 3, (480, 752), 150), (15, 3, (480, 752), 150), (21, 4, (720, 1280), 2000),
+                                                    (9, 2, (240, 320), 300), (31, 2, (480, 752), 200)])
+def test_lk_matches_oracle(dev, win, max_level, shape, n):
+    h, w = shape
+    prev, nxt = synth.shifted_pair(w, h, dx=4, dy=-3, seed=40 + win)
+    nxt = np.clip(nxt.astype(np.int16) + np.random.default_rng(1).integers(-3, 4, nxt.shape), 0, 255).astype(np.uint8)
+    pts = synth.random_points(w, h, n, seed=41, border=-20)   # some points outside the frame on purpose
+    rp, rn = O.Pyramid(prev, win, max_level), O.Pyramid(nxt, win, max_level)
+    ref = O.lk_track(rp, rn, pts, win=win, max_level=max_level, want_iters=True)
+    with _ctx(dev, w, h) as ctx:
+        ctx.upload(0, 0, prev)
+        ctx.upload(0, 1, nxt)
+        ctx.build_pyramid([0, 0], [0, 1], max_level, win)
+        out = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=max_level), want_iters=True)[0]
+    _compare_lk(out, ref)
+    assert np.array_equal(out[3], ref[3])          # identical iteration counts per level
+    assert np.array_equal(out[0], ref[0])          # exact sums on both sides: positions are bit-identical
+
+
+def test_lk_initial_guess_no_initial_flow_and_min_eig(dev):
+    w, h = 376, 240
+    prev, nxt = synth.shifted_pair(w, h, dx=6, dy=5, seed=50)
+    pts = synth.random_points(w, h, 400, seed=51, border=5)
+    guess = pts + np.array([5.0, 4.0], dtype=np.float32)
+    rp, rn = O.Pyramid(prev, 15, 3), O.Pyramid(nxt, 15, 3)
+    with _ctx(dev, w, h) as ctx:
+        ctx.upload(0, 0, prev)
+        ctx.upload(0, 1, nxt)
+        ctx.build_pyramid([0, 0], [0, 1], 3, 15)
+        job = dict(prev=(0, 0), next=(0, 1), prev_xy=pts, guess=guess)
+        for flags in (dev.FT_LK_USE_INITIAL_FLOW, 0, dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_GET_MIN_EIGENVALS):
+            ref = O.lk_track(rp, rn, pts, guess=guess, win=15, max_level=3, flags=flags)
+            out = ctx.lk_track([job], dev.LKParams(win=15, max_level=3, flags=flags))[0]
+            _compare_lk(out, ref)
+            assert np.array_equal(out[2], ref[2])   # err (residual or min eigenvalue) identical
+        # tight termination settings
+        ref = O.lk_track(rp, rn, pts, guess=guess, win=15, max_level=3, max_iter=3, eps=0.1, min_eig=5e-3)
+        out = ctx.lk_track([job], dev.LKParams(win=15, max_level=3, max_iter=3, eps=0.1, min_eig=5e-3))[0]
+        _compare_lk(out, ref)
+        assert (ref[1] == 0).any()
+
+
+def test_lk_forward_backward_and_rect_window(dev):
+    w, h = 640, 360
+    prev, nxt = synth.shifted_pair(w, h, dx=3, dy=2, seed=60)
+    nxt = nxt.copy()
+    nxt[100:180, 200:320] = np.random.default_rng(2).integers(0, 256, (80, 120), dtype=np.uint8)
+    pts = synth.random_points(w, h, 1000, seed=61, border=10)
+    for win in (21, (21, 11)):
+        rp, rn = O.Pyramid(prev, win, 4), O.Pyramid(nxt, win, 4)
+        flags = dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_FORWARD_BACKWARD
+        ref = O.lk_track(rp, rn, pts, win=win, max_level=4, flags=flags, fb_thresh=1.0)
+        with _ctx(dev, w, h) as ctx:
+            ctx.upload(0, 0, prev)
+            ctx.upload(0, 1, nxt)
+            ctx.build_pyramid([0, 0], [0, 1], 4, win)
+            out = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=4, flags=flags, fb_thresh=1.0))[0]
+        _compare_lk(out, ref)
+        assert 0 < (ref[1] == 0).sum() < len(pts)
+
+
+def test_lk_batched_jobs_and_gyro_seed(dev):
+    w, h = 376, 240
+    K4 = np.array([300.0, 300.0, 188.0, 120.0], dtype=np.float32)
+    R, _ = O.integrate_gyro(np.arange(0, 1, 0.005) + 0.001, np.tile([0.01, -0.02, 0.3], (200, 1)), 0.5, 0.55, np.eye(3))
+    jobs, refs = [], []
+    with _ctx(dev, w, h, n_streams=3) as ctx:
+        for s in range(3):
+            prev, nxt = synth.shifted_pair(w, h, dx=2 + s, dy=1 - s, seed=70 + s)
+            pts = synth.random_points(w, h, 100 + 50 * s, seed=71 + s, border=8)
+            ctx.upload(s, 0, prev)
+            ctx.upload(s, 1, nxt)
+            rp, rn = O.Pyramid(prev, 21, 3), O.Pyramid(nxt, 21, 3)
+            guess = O.predict_flow(K4, R, pts)
+            refs.append(O.lk_track(rp, rn, pts, guess=guess, win=21, max_level=3))
+            jobs.append(dict(prev=(s, 0), next=(s, 1), prev_xy=pts, H=ctx.homography(K4, R)))
+        assert np.array_equal(ctx.homography(K4, R), O.homography(K4, R))
+        assert np.abs(ctx.predict_flow(O.homography(K4, R), jobs[0]["prev_xy"]) - O.predict_flow(K4, R, jobs[0]["prev_xy"])).max() <= 1e-4
+        ctx.build_pyramid([0, 1, 2, 0, 1, 2], [0, 0, 0, 1, 1, 1], 3, 21)
+        outs = ctx.lk_track(jobs, dev.LKParams(win=21, max_level=3))
+    for out, ref in zip(outs, refs):
+        _compare_lk(out, ref)
+
+
+@pytest.mark.parametrize("shape,grid,need,thr", [((480, 752), (5, 5), 150, 20), ((720, 1280), (9, 5), 2000, 20),
+                                                  ((480, 752), (5, 5), 30, 10), ((240, 376), (7, 3), 400, 35),
+                                                  ((40, 59), (10, 2), 50, 20)])
+def test_fast_grid_bit_exact(dev, shape, grid, need, thr):
+    h, w = shape
+    img = synth.texture(w, h, seed=80, n_shapes=400)
+    gx, gy = grid
+    per_cell = need // (gx * gy) + 1
+    ref = O.grid_fast(img, need, gx, gy, thr)
+    with _ctx(dev, w, h, max_per_cell=64) as ctx:
+        ctx.upload(0, 0, img)
+        out, n_out, cell_counts = ctx.fast_grid([0], [0], thr, gx, gy, per_cell)
+    got = out[0, : n_out[0]]
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+    # NMS survivor counts per cell equal FAST on each cell view
+    sx, sy = w // gx, h // gy
+    ncx, ncy = w // sx, h // sy
+    for c in range(ncx * ncy):
+        x0, y0 = (c % ncx) * sx, (c // ncx) * sy
+        assert cell_counts[c] == O.fast(img[y0:y0 + sy, x0:x0 + sx], thr).shape[0]
+
+
+def test_fast_grid_batched_and_plateaus(dev):
+    rng = np.random.default_rng(7)
+    imgs = [synth.texture(376, 240, seed=90 + i, n_shapes=300) for i in range(3)]
+    imgs[2] = (imgs[2] // 32 * 32).astype(np.uint8)     # coarse quantisation: plateaus and score ties
+    with _ctx(dev, 376, 240, n_streams=3) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload(i, 0, im)
+        out, n_out, _ = ctx.fast_grid([0, 1, 2], [0, 0, 0], 20, 5, 5, 7)
+    for i, im in enumerate(imgs):
+        ref = O.grid_fast(im, 150, 5, 5, 20)
+        assert np.array_equal(out[i, : n_out[i]], ref)
+
+
+def test_error_codes(dev):
+    with _ctx(dev, 128, 96, n_streams=1) as ctx:
+        with pytest.raises(dev.FtError) as e:
+            ctx.build_pyramid([0], [0], 3, 15)          # no frame yet
+        assert e.value.code == -5
+        with pytest.raises(dev.FtError) as e:
+            ctx.upload(0, 0, np.zeros((200, 200), np.uint8))
+        assert e.value.code == -2
+        with pytest.raises(dev.FtError) as e:
+            ctx.upload(5, 0, np.zeros((96, 128), np.uint8))
+        assert e.value.code == -1
+        ctx.upload(0, 0, np.zeros((96, 128), np.uint8))
+        ctx.build_pyramid([0], [0], 2, 15, with_gradients=False)
+        with pytest.raises(dev.FtError) as e:            # gradients missing
+            ctx.lk_track([dict(prev=(0, 0), next=(0, 0), prev_xy=np.zeros((4, 2), np.float32))], dev.LKParams(win=15, max_level=2))
+        assert e.value.code == -5
