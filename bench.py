@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-frame visual front-end hot path on MI355X.
+
+A step = one frame of every camera stream of the workload through the whole path: frame ingest from HBM, pyramid +
+Scharr gradients, grid FAST (replenishment), gyro-seeded pyramidal LK, host bookkeeping.  The frames are synthetic
+(seeded) and resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg5]
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; every rank runs its own streams (no
+collective in the data path, weak scaling) and rank 0 prints one JSON line with the whole-job rate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: one 752x480 stream, 150 features, 21x21 window, 4 pyramid images, gyro seed
+    "cfg2": dict(desc="1 x 752x480 stream, 150 features, maxLevel 3, win 21, gyro seed (latency-bound single stream)",
+                 streams=1, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1)),
+    # configs[2]: 1280x720, 2000 features, 4 levels, forward-backward
+    "cfg3": dict(desc="1 x 1280x720 stream, 2000 features, maxLevel 4, win 21, forward-backward check",
+                 streams=1, w=1280, h=720, opts=dict(num_pts=2000, win_size=21, pyr_levels=4, forward_backward=1, fb_thresh=1.0,
+                                                     grid_x=9, grid_y=5, use_gyro_seed=1)),
+    # configs[3]: 64 independent 752x480 streams batched (per GPU)
+    "cfg4": dict(desc="64 x 752x480 streams per GPU, 150 features each, maxLevel 3, win 21, gyro seed, batched launches",
+                 streams=64, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1)),
+    # configs[4]: 3840x2160, 10k features, 5 levels, replenishment every frame, one stream per GPU
+    "cfg5": dict(desc="1 x 3840x2160 stream per GPU, 10k features, maxLevel 5, win 21, replenishment every frame",
+                 streams=1, w=3840, h=2160, opts=dict(num_pts=10000, win_size=21, pyr_levels=5, grid_x=26, grid_y=15, use_gyro_seed=1)),
+}
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+
+def level_sizes(w, h, max_level):
+    out = []
+    for _ in range(max_level + 1):
+        out.append((w, h))
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return out
+
+
+def pyramid_kernel_bytes(w, h, max_level):
+    """Algorithmic bytes of the fused pyramid + gradient build of one frame: read every level once, write the
+    gradients (4 B/px) of every level and the next level (1 B/px)."""
+    s = [a * b for a, b in level_sizes(w, h, max_level)]
+    return sum(s) + 4 * sum(s) + sum(s[1:])
+
+
+def make_sequences(wl, n_frames, rank, threads):
+    from feature_tracker_amd import synth
+    return [synth.Sequence(wl["w"], wl["h"], n_frames, stream_id=rank * 1000 + s, threads=threads) for s in range(wl["streams"])]
+
+
+def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0):
+    b = tracker_mod.BatchTracker(wl["streams"], wl["w"], wl["h"], device=device, lib_path=lib_path, **wl["opts"])
+    for s, q in enumerate(seqs):
+        b.set_calibration(s, q.calib8, q.T_cam_imu)
+        for t, g, a in zip(q.imu_t, q.gyro, q.accel):
+            b.feed_imu(s, t, a, g)
+    return b
+
+
+def cpu_baseline(wl, seqs, threads, budget_s=20.0):
+    """The same orchestration on the CPU restatement of the reference path, on a bounded sample of the workload."""
+    import ctypes
+    from feature_tracker_amd import tracker
+    orc_dir = os.path.join(ROOT, "oracle")
+    path = os.path.join(orc_dir, "libft_oracle_tracker.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.fto_set_threads(threads)
+    n_streams = min(wl["streams"], max(1, threads))        # sample: as many streams as threads (one each), same shapes
+    sub = dict(wl, streams=n_streams)
+    b = setup_tracker(tracker, sub, seqs[:n_streams], lib_path=path)
+    n_frames = seqs[0].n_frames
+    ts = lambda i: [q.timestamps[i] for q in seqs[:n_streams]]
+    fr = lambda i: [q.frames[i] for q in seqs[:n_streams]]
+    b.feed_host(ts(0), fr(0))
+    b.feed_host(ts(1), fr(1))
+    tracked, frames, t0 = 0, 0, time.perf_counter()
+    for i in range(2, n_frames):
+        tr, _ = b.feed_host(ts(i), fr(i))
+        tracked += tr
+        frames += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=tracked / dt, unit="tracked_features/s", cores=threads, kind="port",
+                sample=f"{n_streams} stream(s) x {frames} frames of the same workload, {dt:.1f} s, whole path incl. host bookkeeping",
+                ms_per_frame=1e3 * dt / max(1, frames * n_streams))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from feature_tracker_amd import device as ftdev
+    from feature_tracker_amd import tracker
+
+    wl = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+    n_frames = W + K + 1                       # + the first frame, which only detects
+    threads = min(16, os.cpu_count() or 8)
+    t_gen = time.perf_counter()
+    seqs = make_sequences(wl, n_frames, rank, threads)
+    t_gen = time.perf_counter() - t_gen
+
+    # frames resident in HBM before anything is timed
+    S, w, h = wl["streams"], wl["w"], wl["h"]
+    dev_frames = [torch.from_numpy(q.frames).to(dev) for q in seqs]
+    torch.cuda.synchronize()
+    ptrs = [[dev_frames[s][i].data_ptr() for s in range(S)] for i in range(n_frames)]
+    stamps = [[q.timestamps[i] for q in seqs] for i in range(n_frames)]
+
+    b = setup_tracker(tracker, wl, seqs, device=local_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W + 1):
+        b.feed_device(stamps[i], ptrs[i], w, h, w)
+    barrier()
+    t0 = time.perf_counter()
+    tracked = attempted = 0
+    for i in range(W + 1, W + 1 + K):
+        tr, at = b.feed_device(stamps[i], ptrs[i], w, h, w)
+        tracked += tr
+        attempted += at
+    barrier()
+    dt = time.perf_counter() - t0
+
+    # ---- per-kernel device time over the same K steps (HIP events on the tracker's own queue) ----
+    lib = ftdev.load_library()
+    import ctypes as C
+    ctx = C.c_void_p(b.device_ctx())
+    b2 = setup_tracker(tracker, wl, seqs, device=local_rank)
+    ctx2 = C.c_void_p(b2.device_ctx())
+    for i in range(W + 1):
+        b2.feed_device(stamps[i], ptrs[i], w, h, w)
+    lib.ft_profile(ctx2, 1)
+    for i in range(W + 1, W + 1 + K):
+        b2.feed_device(stamps[i], ptrs[i], w, h, w)
+    kt = ftdev.ft_kernel_time()
+    lib.ft_kernel_times(ctx2, C.byref(kt), 1)
+    lib.ft_profile(ctx2, 0)
+    del ctx
+
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        c = torch.tensor([tracked, attempted], device=dev, dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tracked_all, attempted_all = float(c[0].item()), float(c[1].item())
+    else:
+        dt_max, tracked_all, attempted_all = dt, float(tracked), float(attempted)
+
+    if rank == 0:
+        pyr_bytes = pyramid_kernel_bytes(w, h, wl["opts"]["pyr_levels"]) * S     # per launch group (one step)
+        kinds = {
+            "pyramid_gradient": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
+            "lk_track": (kt.lk_ms, kt.lk_launches, None),
+            "fast_grid": (kt.fast_ms, kt.fast_launches, w * h * S),
+        }
+        per_kernel = {}
+        for name, (ms, n, by) in kinds.items():
+            if n:
+                avg = ms / n
+                e = dict(avg_ms=avg, launches=n, share_of_step=avg / (1e3 * dt / K))
+                if by:
+                    e.update(algorithmic_bytes=by, achieved_gbs=by / (avg * 1e-3) / 1e9, frac_hbm_peak=by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                per_kernel[name] = e
+        pk = per_kernel.get("pyramid_gradient", {})
+        roofline = dict(kernel="level_kernel (fused pyrDown + Scharr, all levels of all streams of one step)", bound="hbm",
+                        achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=pk.get("frac_hbm_peak"), traffic=None)
+        out = {
+            "metric": "tracked_features_per_sec", "value": tracked_all / dt_max, "unit": "features/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i16 images, i32 exact sums, f32 solve", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": S, "width": w, "height": h,
+                       "features_per_stream": wl["opts"]["num_pts"], "window": wl["opts"]["win_size"],
+                       "max_level": wl["opts"]["pyr_levels"], "frames_in_hbm": True},
+            "tracked_fraction": tracked_all / max(1.0, attempted_all),
+            "frames_per_sec": world * S * K / dt_max,
+            "roofline": roofline,
+            "kernels": per_kernel,
+            "setup": {"sequence_generation_s": t_gen},
+        }
+        if not args.no_latency:
+            out["latency"] = single_stream_latency(tracker, local_rank)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, seqs, threads)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def single_stream_latency(tracker, device, n=120):
+    """p50/p95 of one 752x480 frame, host pointer in -> tracked points readable on the host (BASELINE configs[1])."""
+    wl = WORKLOADS["cfg2"]
+    from feature_tracker_amd import synth
+    q = synth.Sequence(wl["w"], wl["h"], n + 10, stream_id=99)
+    b = setup_tracker(tracker, wl, [q], device=device)
+    lat = []
+    for i in range(n + 10):
+        t0 = time.perf_counter()
+        b.feed_host([q.timestamps[i]], [q.frames[i]])
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat[10:]) * 1e3
+    return {"workload": "cfg2: " + wl["desc"] + ", frame uploaded from host memory", "p50_ms": float(np.percentile(lat, 50)),
+            "p95_ms": float(np.percentile(lat, 95)), "frames": n}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+// Options of the visual front-end.  The first block keeps the reference's field names and defaults
+// (src/FeatureTrackerOptions.h:28-51); the second block promotes values the reference hard-codes
+// (src/track/TrackKLT.h:121-122, src/track/TrackKLT.cpp:305,:401) because other configurations vary them.
+#pragma once
+#include <cstdio>
+#include <map>
+#include <utility>
+
+#include "types.h"
+
+namespace feature_tracker {
+
+struct FeatureTrackerOptions {
+    int num_cameras = 2;
+
+    // ---- tracker ----
+    bool use_klt = true;        // KLT tracking (the descriptor matcher is not part of this build)
+    int num_pts = 150;          // points extracted and tracked in each image
+    int fast_threshold = 20;    // FAST extraction threshold
+    int grid_x = 5;             // detection grid columns
+    int grid_y = 5;             // detection grid rows
+    int min_px_dist = 10;       // minimum spacing between tracked features
+    double knn_ratio = 0.85;    // descriptor matcher only
+
+    // ---- promoted constants (defaults = the reference's hard-coded values) ----
+    int pyr_levels = 3;         // LK maxLevel
+    int win_size = 15;          // LK window side
+    int lk_max_iter = 15;       // TermCriteria COUNT
+    double lk_eps = 0.01;       // TermCriteria EPS
+    double lk_min_eig = 1e-4;   // calcOpticalFlowPyrLK minEigThreshold
+    bool use_gyro_seed = false; // seed temporal LK with the gyro-predicted flow
+    bool forward_backward = false;
+    float fb_thresh = 1.0f;     // px
+    bool speculative_detect = true;   // run the detector on every new frame so replenishment needs no extra sync
+
+    void print_trackers() const {
+        printf("FEATURE TRACKING PARAMETERS:\n");
+        printf("\t- num_pts: %d\n", num_pts);
+        printf("\t- fast_threshold: %d\n\t- grid: %d x %d\n\t- min_px_dist: %d\n", fast_threshold, grid_x, grid_y, min_px_dist);
+        printf("\t- lk: win %d, levels %d, term (%d, %g), gyro seed %d, forward-backward %d\n", win_size, pyr_levels,
+               lk_max_iter, lk_eps, (int)use_gyro_seed, (int)forward_backward);
+    }
+
+    // ---- camera model ----
+    std::map<size_t, Calib8> camera_intrinsics;          // fx, fy, cx, cy, d1..d4
+    std::map<size_t, std::array<double, 7>> camera_extrinsics;   // q_ItoC (JPL xyzw), p_IinC
+    std::map<size_t, Mat4d> camera_extrinsics_mat;       // T_cam_imu as a 4x4 matrix
+    std::map<size_t, std::pair<int, int>> camera_wh;     // (width, height)
+
+    void print_state() const {
+        printf("STATE PARAMETERS:\n");
+        for (const auto& kv : camera_intrinsics) {
+            const auto wh = camera_wh.count(kv.first) ? camera_wh.at(kv.first) : std::make_pair(0, 0);
+            printf("cam_%zu_wh: %d x %d\ncam_%zu_intrinsic: %g %g %g %g | %g %g %g %g\n", kv.first, wh.first, wh.second, kv.first,
+                   kv.second[0], kv.second[1], kv.second[2], kv.second[3], kv.second[4], kv.second[5], kv.second[6], kv.second[7]);
+        }
+    }
+};
+
+}  // namespace feature_tracker

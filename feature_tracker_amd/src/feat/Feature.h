@@ -1,0 +1,56 @@
+// One tracked landmark: per-camera raw and normalized observations with their timestamps
+// (mirrors the members of src/feat/Feature.h:39-90 that the tracker fills).
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstddef>
+#include <unordered_map>
+#include <vector>
+
+namespace feature_tracker {
+
+class Feature {
+public:
+    size_t featid = 0;
+    bool to_delete = false;
+    std::unordered_map<size_t, std::vector<std::array<float, 2>>> uvs;        // raw pixels per camera
+    std::unordered_map<size_t, std::vector<std::array<float, 2>>> uvs_norm;   // undistorted, normalized
+    std::unordered_map<size_t, std::vector<double>> timestamps;
+    int anchor_cam_id = -1;
+    double anchor_clone_timestamp = 0.0;
+    std::array<double, 3> p_FinA{{0, 0, 0}};
+    std::array<double, 3> p_FinG{{0, 0, 0}};
+
+    // keep only measurements taken at one of valid_times (src/feat/Feature.cpp:29-58)
+    void clean_old_measurements(const std::vector<double>& valid_times) {
+        filter([&](double t) { return std::find(valid_times.begin(), valid_times.end(), t) != valid_times.end(); });
+    }
+    // drop measurements at or before timestamp (src/feat/Feature.cpp:60-89)
+    void clean_older_measurements(double timestamp) {
+        filter([&](double t) { return t > timestamp; });
+    }
+    size_t num_measurements() const {
+        size_t n = 0;
+        for (const auto& kv : timestamps) n += kv.second.size();
+        return n;
+    }
+
+private:
+    template <class Keep>
+    void filter(Keep keep) {
+        for (auto& kv : timestamps) {
+            auto& ts = kv.second;
+            auto& a = uvs[kv.first];
+            auto& b = uvs_norm[kv.first];
+            size_t o = 0;
+            for (size_t i = 0; i < ts.size(); i++) {
+                if (!keep(ts[i])) continue;
+                ts[o] = ts[i]; a[o] = a[i]; b[o] = b[i];
+                o++;
+            }
+            ts.resize(o); a.resize(o); b.resize(o);
+        }
+    }
+};
+
+}  // namespace feature_tracker

@@ -1,0 +1,125 @@
+// Track database: id -> Feature under one mutex (call surface of src/feat/FeatureDatabase.h:53-327).
+// Features handed out with remove=true become the caller's to delete, as in the reference.
+#pragma once
+#include <functional>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "Feature.h"
+
+namespace feature_tracker {
+
+class FeatureDatabase {
+public:
+    FeatureDatabase() = default;
+    FeatureDatabase(const FeatureDatabase&) = delete;
+    FeatureDatabase& operator=(const FeatureDatabase&) = delete;
+    ~FeatureDatabase() {
+        for (auto& kv : features_idlookup) delete kv.second;
+    }
+
+    Feature* get_feature(size_t id, bool remove = false) {
+        std::lock_guard<std::mutex> lck(mtx);
+        auto it = features_idlookup.find(id);
+        if (it == features_idlookup.end()) return nullptr;
+        Feature* f = it->second;
+        if (remove) features_idlookup.erase(it);
+        return f;
+    }
+
+    // append one observation; creates the feature the first time its id is seen (FeatureDatabase.h:96-123)
+    void update_feature(size_t id, double timestamp, size_t cam_id, float u, float v, float u_n, float v_n) {
+        std::lock_guard<std::mutex> lck(mtx);
+        Feature*& f = features_idlookup[id];
+        if (!f) {
+            f = new Feature();
+            f->featid = id;
+        }
+        f->uvs[cam_id].push_back({{u, v}});
+        f->uvs_norm[cam_id].push_back({{u_n, v_n}});
+        f->timestamps[cam_id].push_back(timestamp);
+    }
+
+    // features whose newest measurement in every camera is older than timestamp (FeatureDatabase.h:133-166)
+    std::vector<Feature*> features_not_containing_newer(double timestamp, bool remove = false) {
+        return collect(remove, [&](const Feature& f) {
+            for (const auto& kv : f.timestamps)
+                if (!kv.second.empty() && kv.second.back() >= timestamp) return false;
+            return true;
+        });
+    }
+    // features with a first measurement before timestamp in some camera (FeatureDatabase.h:175-207)
+    std::vector<Feature*> features_containing_older(double timestamp, bool remove = false) {
+        return collect(remove, [&](const Feature& f) {
+            for (const auto& kv : f.timestamps)
+                if (!kv.second.empty() && kv.second.front() < timestamp) return true;
+            return false;
+        });
+    }
+    // features with a measurement exactly at timestamp (FeatureDatabase.h:215-255)
+    std::vector<Feature*> features_containing(double timestamp, bool remove = false) {
+        return collect(remove, [&](const Feature& f) {
+            for (const auto& kv : f.timestamps)
+                for (double t : kv.second)
+                    if (t == timestamp) return true;
+            return false;
+        });
+    }
+
+    // delete features flagged to_delete (FeatureDatabase.h:262-278)
+    void cleanup() {
+        std::lock_guard<std::mutex> lck(mtx);
+        for (auto it = features_idlookup.begin(); it != features_idlookup.end();) {
+            if (it->second->to_delete) { delete it->second; it = features_idlookup.erase(it); }
+            else ++it;
+        }
+    }
+    // drop measurements at or before timestamp and features left without any (FeatureDatabase.h:283-301)
+    void cleanup_measurements(double timestamp) {
+        std::lock_guard<std::mutex> lck(mtx);
+        for (auto it = features_idlookup.begin(); it != features_idlookup.end();) {
+            it->second->clean_older_measurements(timestamp);
+            if (it->second->num_measurements() < 1) { delete it->second; it = features_idlookup.erase(it); }
+            else ++it;
+        }
+    }
+
+    size_t size() {
+        std::lock_guard<std::mutex> lck(mtx);
+        return features_idlookup.size();
+    }
+    std::unordered_map<size_t, Feature*> get_internal_data() {
+        std::lock_guard<std::mutex> lck(mtx);
+        return features_idlookup;
+    }
+    // re-key a feature (used by TrackBase::change_feat_id)
+    void rekey(size_t id_old, size_t id_new) {
+        std::lock_guard<std::mutex> lck(mtx);
+        auto it = features_idlookup.find(id_old);
+        if (it == features_idlookup.end()) return;
+        Feature* f = it->second;
+        features_idlookup.erase(it);
+        f->featid = id_new;
+        features_idlookup[id_new] = f;
+    }
+
+protected:
+    std::vector<Feature*> collect(bool remove, const std::function<bool(const Feature&)>& pred) {
+        std::vector<Feature*> out;
+        std::lock_guard<std::mutex> lck(mtx);
+        for (auto it = features_idlookup.begin(); it != features_idlookup.end();) {
+            if (pred(*it->second)) {
+                out.push_back(it->second);
+                if (remove) { it = features_idlookup.erase(it); continue; }
+            }
+            ++it;
+        }
+        return out;
+    }
+
+    std::mutex mtx;
+    std::unordered_map<size_t, Feature*> features_idlookup;
+};
+
+}  // namespace feature_tracker

@@ -1,0 +1,224 @@
+// C wrapper of the host tracker layer (include/ft_tracker.h).  The backend is created by ftk_make_backend(),
+// which each library that compiles this file defines: the product library binds the gfx950 device layer.
+#include "ft_tracker.h"
+
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "FeatureTrackerOptions.h"
+#include "track/TrackKLT.h"
+#include "track/TrackKLTBatch.h"
+
+using namespace feature_tracker;
+
+// defined once per library: which FrontendBackend the trackers of that library run on
+FrontendBackend* ftk_make_backend(int device, const ft_limits& limits, void** device_ctx);
+const char* ftk_backend_label();
+
+namespace {
+
+FeatureTrackerOptions to_options(const ftk_options& o) {
+    FeatureTrackerOptions r;
+    r.num_pts = o.num_pts; r.fast_threshold = o.fast_threshold; r.grid_x = o.grid_x; r.grid_y = o.grid_y;
+    r.min_px_dist = o.min_px_dist; r.pyr_levels = o.pyr_levels; r.win_size = o.win_size; r.lk_max_iter = o.lk_max_iter;
+    r.lk_eps = o.lk_eps; r.lk_min_eig = o.lk_min_eig; r.use_gyro_seed = o.use_gyro_seed != 0;
+    r.forward_backward = o.forward_backward != 0; r.fb_thresh = o.fb_thresh; r.speculative_detect = o.speculative_detect != 0;
+    return r;
+}
+
+ft_limits limits_for(const ftk_options& o, int n_streams, int w, int h) {
+    ft_limits L;
+    L.max_width = w; L.max_height = h;
+    L.max_levels = o.pyr_levels + 1;
+    L.n_streams = n_streams;
+    L.n_slots = 2;
+    L.max_points = n_streams * (o.num_pts + o.grid_x * o.grid_y + 64);
+    // a cell can be narrower than cols/grid_x suggests only in degenerate geometry; leave room for that
+    L.max_grid_cells = (o.grid_x + 2) * (o.grid_y + 2);
+    L.max_per_cell = o.num_pts / (o.grid_x * o.grid_y) + 1;
+    return L;
+}
+
+bool valid_options(const ftk_options* o) {
+    return o && o->num_pts > 0 && o->grid_x > 0 && o->grid_y > 0 && o->min_px_dist > 0 && o->pyr_levels >= 0 &&
+           o->pyr_levels < FT_MAX_LEVELS && o->win_size >= 3 && o->win_size <= FT_MAX_WIN;
+}
+
+int get_points(TrackKLT& t, int cam, float* xy, uint64_t* ids, int cap) {
+    const std::vector<KeyPoint> p = t.get_last_points((size_t)cam);
+    const std::vector<size_t> id = t.get_last_ids((size_t)cam);
+    for (size_t i = 0; i < p.size() && (int)i < cap; i++) {
+        if (xy) { xy[2 * i] = p[i].pt.x; xy[2 * i + 1] = p[i].pt.y; }
+        if (ids) ids[i] = (uint64_t)id[i];
+    }
+    return (int)p.size();
+}
+
+void calib_maps(int n_cams, const double* calib8, const double* T, std::map<size_t, Calib8>& K, std::map<size_t, Mat4d>& E) {
+    for (int c = 0; c < n_cams; c++) {
+        Calib8 k;
+        Mat4d e;
+        for (int i = 0; i < 8; i++) k[i] = calib8[8 * c + i];
+        for (int i = 0; i < 16; i++) e[i] = T ? T[16 * c + i] : ((i % 5 == 0) ? 1.0 : 0.0);
+        K[(size_t)c] = k; E[(size_t)c] = e;
+    }
+}
+
+}  // namespace
+
+struct ftk_tracker {
+    std::unique_ptr<FrontendBackend> be;
+    std::unique_ptr<TrackKLT> trk;
+};
+
+struct ftk_batch {
+    std::unique_ptr<FrontendBackend> be;
+    std::unique_ptr<TrackKLTBatch> batch;
+    void* device_ctx = nullptr;
+    std::vector<FrameSource> frames;
+};
+
+extern "C" {
+
+void ftk_default_options(ftk_options* o) {
+    if (!o) return;
+    const FeatureTrackerOptions d;
+    o->num_pts = d.num_pts; o->fast_threshold = d.fast_threshold; o->grid_x = d.grid_x; o->grid_y = d.grid_y;
+    o->min_px_dist = d.min_px_dist; o->pyr_levels = d.pyr_levels; o->win_size = d.win_size; o->lk_max_iter = d.lk_max_iter;
+    o->lk_eps = d.lk_eps; o->lk_min_eig = d.lk_min_eig; o->use_gyro_seed = d.use_gyro_seed; o->forward_backward = d.forward_backward;
+    o->fb_thresh = d.fb_thresh; o->speculative_detect = d.speculative_detect;
+}
+
+const char* ftk_backend_name(void) { return ftk_backend_label(); }
+
+int ftk_tracker_create(ftk_tracker** out, int device, const ftk_options* o, int max_width, int max_height) {
+    if (!out || !valid_options(o) || max_width < 1 || max_height < 1) return FT_E_INVALID;
+    *out = nullptr;
+    try {
+        std::unique_ptr<ftk_tracker> t(new ftk_tracker());
+        void* dctx = nullptr;
+        t->be.reset(ftk_make_backend(device, limits_for(*o, 2, max_width, max_height), &dctx));
+        if (!t->be) return FT_E_NODEVICE;
+        t->trk.reset(new TrackKLT(t->be.get(), to_options(*o), 0, 0));
+        *out = t.release();
+        return FT_OK;
+    } catch (const std::bad_alloc&) {
+        return FT_E_NOMEM;
+    } catch (...) {
+        return FT_E_HIP;
+    }
+}
+
+void ftk_tracker_destroy(ftk_tracker* t) { delete t; }
+
+int ftk_tracker_set_calibration(ftk_tracker* t, int n_cams, const double* calib8, const double* T_cam_imu) {
+    if (!t || n_cams < 1 || !calib8) return FT_E_INVALID;
+    std::map<size_t, Calib8> K;
+    std::map<size_t, Mat4d> E;
+    calib_maps(n_cams, calib8, T_cam_imu, K, E);
+    t->trk->set_calibration(K, E);
+    return FT_OK;
+}
+
+int ftk_tracker_feed_imu(ftk_tracker* t, double timestamp, const double* am3, const double* wm3) {
+    if (!t || !am3 || !wm3) return FT_E_INVALID;
+    t->trk->feed_imu(timestamp, Vec3d{{am3[0], am3[1], am3[2]}}, Vec3d{{wm3[0], wm3[1], wm3[2]}});
+    return FT_OK;
+}
+
+int ftk_tracker_feed_stereo(ftk_tracker* t, double timestamp, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
+                            int cam_left, int cam_right) {
+    if (!t || !left || !right || w < 1 || h < 1 || cam_left < 0 || cam_right < 0 || cam_left > 1 || cam_right > 1) return FT_E_INVALID;
+    t->trk->feed_stereo(timestamp, Image8(left, w, h, stride), Image8(right, w, h, stride), (size_t)cam_left, (size_t)cam_right);
+    return FT_OK;
+}
+
+int ftk_tracker_feed_monocular(ftk_tracker* t, double timestamp, const uint8_t* img, int w, int h, size_t stride, int cam) {
+    if (!t || !img || w < 1 || h < 1 || cam < 0 || cam > 1) return FT_E_INVALID;
+    t->trk->feed_monocular(timestamp, Image8(img, w, h, stride), (size_t)cam);
+    return FT_OK;
+}
+
+int ftk_tracker_get_points(ftk_tracker* t, int cam, float* xy, uint64_t* ids, int cap) {
+    if (!t) return FT_E_INVALID;
+    return get_points(*t->trk, cam, xy, ids, cap);
+}
+
+int ftk_tracker_database_size(ftk_tracker* t) { return t ? (int)t->trk->get_feature_database()->size() : FT_E_INVALID; }
+
+int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap) {
+    if (!t) return FT_E_INVALID;
+    Feature* f = t->trk->get_feature_database()->get_feature((size_t)id);
+    if (!f || !f->timestamps.count((size_t)cam)) return 0;
+    const auto& ts = f->timestamps.at((size_t)cam);
+    for (size_t i = 0; i < ts.size() && (int)i < cap; i++) {
+        if (uvn4) {
+            uvn4[4 * i] = f->uvs.at((size_t)cam)[i][0]; uvn4[4 * i + 1] = f->uvs.at((size_t)cam)[i][1];
+            uvn4[4 * i + 2] = f->uvs_norm.at((size_t)cam)[i][0]; uvn4[4 * i + 3] = f->uvs_norm.at((size_t)cam)[i][1];
+        }
+        if (timestamps) timestamps[i] = ts[i];
+    }
+    return (int)ts.size();
+}
+
+int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height) {
+    if (!out || !valid_options(o) || n_streams < 1 || n_streams > FT_MAX_BATCH || max_width < 1 || max_height < 1) return FT_E_INVALID;
+    *out = nullptr;
+    try {
+        std::unique_ptr<ftk_batch> b(new ftk_batch());
+        b->be.reset(ftk_make_backend(device, limits_for(*o, n_streams, max_width, max_height), &b->device_ctx));
+        if (!b->be) return FT_E_NODEVICE;
+        b->batch.reset(new TrackKLTBatch(b->be.get(), to_options(*o), n_streams));
+        b->frames.resize(n_streams);
+        *out = b.release();
+        return FT_OK;
+    } catch (const std::bad_alloc&) {
+        return FT_E_NOMEM;
+    } catch (...) {
+        return FT_E_HIP;
+    }
+}
+
+void ftk_batch_destroy(ftk_batch* b) { delete b; }
+
+int ftk_batch_set_calibration(ftk_batch* b, int stream, const double* calib8, const double* T_cam_imu) {
+    if (!b || stream < 0 || stream >= b->batch->size() || !calib8) return FT_E_INVALID;
+    std::map<size_t, Calib8> K;
+    std::map<size_t, Mat4d> E;
+    calib_maps(1, calib8, T_cam_imu, K, E);
+    b->batch->tracker(stream).set_calibration(K, E);
+    return FT_OK;
+}
+
+int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double* am3, const double* wm3) {
+    if (!b || stream < 0 || stream >= b->batch->size() || !am3 || !wm3) return FT_E_INVALID;
+    b->batch->tracker(stream).feed_imu(timestamp, Vec3d{{am3[0], am3[1], am3[2]}}, Vec3d{{wm3[0], wm3[1], wm3[2]}});
+    return FT_OK;
+}
+
+int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
+                   size_t stride, long long* tracked, long long* attempted) {
+    if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
+    const int S = b->batch->size();
+    for (int s = 0; s < S; s++) {
+        if (!frames[s]) return FT_E_INVALID;
+        FrameSource& f = b->frames[s];
+        f = FrameSource();
+        if (frames_on_device) f.dev = frames[s]; else f.host = (const uint8_t*)frames[s];
+        f.cols = w; f.rows = h; f.step = stride;
+    }
+    const int rc = b->batch->feed(timestamps, b->frames.data());
+    if (tracked) *tracked = (long long)b->batch->tracked_features();
+    if (attempted) *attempted = (long long)b->batch->attempted_features();
+    return rc;
+}
+
+int ftk_batch_get_points(ftk_batch* b, int stream, float* xy, uint64_t* ids, int cap) {
+    if (!b || stream < 0 || stream >= b->batch->size()) return FT_E_INVALID;
+    return get_points(b->batch->tracker(stream), 0, xy, ids, cap);
+}
+
+void* ftk_batch_device_ctx(ftk_batch* b) { return b ? b->device_ctx : nullptr; }
+
+}  // extern "C"

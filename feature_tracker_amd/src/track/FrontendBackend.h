@@ -1,0 +1,27 @@
+// Abstract mirror of the device C ABI (include/ft_device.h).  The tracker classes talk to this interface; the
+// product build binds it to the gfx950 library (HipBackend.h).  Tests bind a CPU checker behind the same
+// interface to time and verify the identical orchestration code.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "ft_device.h"
+
+namespace feature_tracker {
+
+class FrontendBackend {
+public:
+    virtual ~FrontendBackend() = default;
+    virtual int upload(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) = 0;
+    virtual int set_frame_device(int stream, int slot, const void* dev, int w, int h, size_t stride) = 0;
+    virtual int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
+                              int with_gradients, int* achieved) = 0;
+    virtual int lk_track_async(int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) = 0;
+    virtual int fast_grid_async(int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
+                                int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts) = 0;
+    virtual void homography(const float* K4, const float* R_p_c, float* H) = 0;
+    virtual int sync() = 0;
+    virtual const char* name() const = 0;
+};
+
+}  // namespace feature_tracker

@@ -1,0 +1,46 @@
+// FrontendBackend bound to the gfx950 device library through its C ABI.
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "FrontendBackend.h"
+
+namespace feature_tracker {
+
+class HipBackend : public FrontendBackend {
+public:
+    HipBackend(int device, const ft_limits& limits) {
+        const int rc = ft_ctx_create(&ctx_, device, &limits);
+        if (rc != FT_OK) throw std::runtime_error(std::string("ft_ctx_create: ") + ft_strerror(rc));
+    }
+    ~HipBackend() override { ft_ctx_destroy(ctx_); }
+    HipBackend(const HipBackend&) = delete;
+    HipBackend& operator=(const HipBackend&) = delete;
+
+    int upload(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) override {
+        return ft_upload(ctx_, stream, slot, host, w, h, stride);
+    }
+    int set_frame_device(int stream, int slot, const void* dev, int w, int h, size_t stride) override {
+        return ft_set_frame_device(ctx_, stream, slot, dev, w, h, stride);
+    }
+    int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h, int with_gradients,
+                      int* achieved) override {
+        return ft_build_pyramid(ctx_, n, streams, slots, max_level, win_w, win_h, with_gradients, achieved);
+    }
+    int lk_track_async(int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) override {
+        return ft_lk_track_async(ctx_, n_jobs, jobs, prm);
+    }
+    int fast_grid_async(int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y, int per_cell,
+                        ft_keypoint* out, int cap, int* n_out, int* cell_counts) override {
+        return ft_fast_grid_async(ctx_, n, streams, slots, threshold, grid_x, grid_y, per_cell, out, cap, n_out, cell_counts);
+    }
+    void homography(const float* K4, const float* R_p_c, float* H) override { ft_homography(K4, R_p_c, H); }
+    int sync() override { return ft_sync(ctx_); }
+    const char* name() const override { return "hip-gfx950"; }
+    ft_ctx* ctx() { return ctx_; }
+
+private:
+    ft_ctx* ctx_ = nullptr;
+};
+
+}  // namespace feature_tracker

@@ -1,0 +1,457 @@
+// Orchestration of the KLT front-end on top of the batched device kernels.  Follows the control flow of
+// src/track/TrackKLT.cpp:27-432 (feed_stereo, perform_detection_stereo, perform_matching).
+#include "TrackKLT.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace feature_tracker {
+
+ft_lk_params TrackKLT::lk_params() const {
+    ft_lk_params p;
+    p.win_w = win_size; p.win_h = win_size;
+    p.max_level = pyr_levels;
+    p.max_iter = lk_max_iter;                // TermCriteria(COUNT + EPS, 15, 0.01), TrackKLT.cpp:305,:401
+    p.eps = lk_eps;
+    p.min_eig = lk_min_eig;
+    p.flags = FT_LK_USE_INITIAL_FLOW | (forward_backward ? FT_LK_FORWARD_BACKWARD : 0);
+    p.fb_thresh = fb_thresh;
+    return p;
+}
+
+void TrackKLT::filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, std::vector<size_t>& ids) {
+    size_t o = 0;
+    for (size_t i = 0; i < pts.size(); i++) {
+        if (occ.taken(pts[i].pt)) continue;   // too close to an earlier point: drop it (TrackKLT.cpp:238-242)
+        occ.take(pts[i].pt);
+        pts[o] = pts[i]; ids[o] = ids[i];
+        o++;
+    }
+    pts.resize(o); ids.resize(o);
+}
+
+// first num_needed/(grid_x*grid_y)+1 entries of every cell of a ranked detection (Grider_FAST.h:88,:118-130)
+std::vector<KeyPoint> TrackKLT::select_from_detection(const Detection& det, int num_needed, int grid_x, int grid_y) {
+    std::vector<KeyPoint> out;
+    if (!det.valid) return out;
+    const int k = std::min(num_needed / (grid_x * grid_y) + 1, det.per_cell);
+    int off = 0;
+    for (int c = 0; c < det.cells; c++) {
+        const int kept = std::min(det.cell_counts[c], det.per_cell);
+        for (int r = 0; r < kept && r < k && off + r < det.n; r++) out.push_back(Grider_FAST::to_keypoint(det.kps[off + r]));
+        off += kept;
+    }
+    return out;
+}
+
+bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float* H) {
+    if (!use_gyro_seed || !camera_k.count(cam_id)) return false;
+    Mat3f R0, R1;
+    const int used = propagator->integrate_by_msckfVio(t_last, t_cur, R0, R1, false);
+    if (used <= 0) return false;
+    const auto& K = camera_k.at(cam_id);
+    const float K4[4] = {(float)K[0], (float)K[1], (float)K[2], (float)K[3]};
+    be->homography(K4, (cam_id == 1 ? R1 : R0).data(), H);   // H = K R K^-1 (TrackMsckfVio.cpp:348-349)
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// monocular path
+// ---------------------------------------------------------------------------------------------------------------
+
+int TrackKLT::mono_begin(double timestamp, const FrameSource& frame, size_t cam_id, MonoPlan& plan) {
+    CamState& cs = cams[cam_id];
+    plan = MonoPlan();
+    plan.cam = cam_id;
+    plan.timestamp = timestamp;
+    plan.stream = stream0 + (int)cam_id;
+    plan.slot_last = cs.slot_last;
+    plan.slot_cur = cs.slot_last == 0 ? 1 : 0;
+    plan.cols = frame.cols; plan.rows = frame.rows;
+    if (frame.dev) return be->set_frame_device(plan.stream, plan.slot_cur, frame.dev, frame.cols, frame.rows, frame.step);
+    return be->upload(plan.stream, plan.slot_cur, frame.host, frame.cols, frame.rows, frame.step);
+}
+
+int TrackKLT::mono_features_needed(const MonoPlan& plan) {
+    const CamState& cs = cams[plan.cam];
+    auto& pts = pts_last[plan.cam];
+    if (cs.slot_last < 0 || pts.empty()) return 0;   // first frame: detection happens on the current frame
+    // the occupancy filter can only shrink the set, so count after applying it
+    Occupancy occ(cs.cols, cs.rows, min_px_dist);
+    filter_by_occupancy(occ, pts, ids_last[plan.cam]);
+    return num_features - (int)pts.size();
+}
+
+void TrackKLT::perform_detection_monocular(int cols, int rows, const Detection& det, std::vector<KeyPoint>& pts0, std::vector<size_t>& ids0) {
+    Occupancy occ(cols, rows, min_px_dist);
+    filter_by_occupancy(occ, pts0, ids0);
+    const int num_featsneeded = num_features - (int)pts0.size();
+    if (num_featsneeded > 1) {                                   // "> 1", as TrackKLT.cpp:271
+        for (const KeyPoint& kpt : select_from_detection(det, num_featsneeded, grid_x, grid_y)) {
+            if (occ.taken(kpt.pt)) continue;                     // TrackKLT.cpp:280-288
+            occ.take(kpt.pt);
+            pts0.push_back(kpt);
+            ids0.push_back(++currid);
+        }
+    }
+}
+
+void TrackKLT::mono_prepare(MonoPlan& plan, const Detection& last_det, ft_lk_job& job) {
+    CamState& cs = cams[plan.cam];
+    auto& pts = pts_last[plan.cam];
+    auto& ids = ids_last[plan.cam];
+    memset(&job, 0, sizeof(job));
+    if (cs.slot_last < 0 || pts.empty()) {   // TrackKLT.cpp:63-72
+        plan.first = true;
+        return;
+    }
+    // top the previous frame up so that a constant number of features is tracked (TrackKLT.cpp:76-78)
+    perform_detection_monocular(cs.cols, cs.rows, last_det, pts, ids);
+    if (pts.size() < 10) {                   // not enough points: all-zero mask (TrackKLT.cpp:392-396)
+        plan.reset = true;
+        return;
+    }
+    const size_t n = pts.size();
+    plan.prev_xy.resize(2 * n); plan.next_xy.resize(2 * n); plan.err.resize(n); plan.status.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        plan.prev_xy[2 * i] = pts[i].pt.x; plan.prev_xy[2 * i + 1] = pts[i].pt.y;
+    }
+    plan.next_xy = plan.prev_xy;             // initial guess = previous position (TrackKLT.cpp:87-88)
+    plan.use_H = gyro_homography(plan.cam, cs.t_last, plan.timestamp, plan.H);
+    plan.run_lk = true;
+    job.stream_prev = plan.stream; job.slot_prev = cs.slot_last;
+    job.stream_next = plan.stream; job.slot_next = plan.slot_cur;
+    job.n = (int)n;
+    job.prev_xy = plan.prev_xy.data(); job.next_xy = plan.next_xy.data();
+    job.status = plan.status.data(); job.err = plan.err.data();
+    job.H = plan.use_H ? plan.H : nullptr;
+    job.iters = nullptr;
+}
+
+void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
+    CamState& cs = cams[plan.cam];
+    auto& pts = pts_last[plan.cam];
+    auto& ids = ids_last[plan.cam];
+    if (plan.first) {
+        pts.clear(); ids.clear();
+        perform_detection_monocular(plan.cols, plan.rows, cur_det, pts, ids);
+    } else if (plan.reset || !plan.run_lk) {
+        pts.clear(); ids.clear();            // lost tracking: re-detect on the next frame (TrackKLT.cpp:118-129)
+    } else {
+        std::vector<KeyPoint> good;
+        std::vector<size_t> good_ids;
+        good.reserve(pts.size()); good_ids.reserve(pts.size());
+        for (size_t i = 0; i < pts.size(); i++) {
+            const float x = plan.next_xy[2 * i], y = plan.next_xy[2 * i + 1];
+            if (x < 0 || y < 0) continue;    // TrackKLT.cpp:138
+            if (!plan.status[i]) continue;
+            KeyPoint kp = pts[i];
+            kp.pt = Point2f(x, y);
+            good.push_back(kp);
+            good_ids.push_back(ids[i]);
+        }
+        if (camera_k.count(plan.cam)) {
+            for (size_t i = 0; i < good.size(); i++) {   // TrackKLT.cpp:187-192
+                const Point2f npt = undistort_point(good[i].pt, plan.cam);
+                database->update_feature(good_ids[i], plan.timestamp, plan.cam, good[i].pt.x, good[i].pt.y, npt.x, npt.y);
+            }
+        }
+        pts.swap(good);
+        ids.swap(good_ids);
+    }
+    // keep the ranked detection of this frame for the next call
+    cache_valid = cur_det.valid;
+    if (cur_det.valid) {
+        cache_kps.assign(cur_det.kps, cur_det.kps + cur_det.n);
+        cache_cell_counts.assign(cur_det.cell_counts, cur_det.cell_counts + cur_det.cells);
+        cache_per_cell = cur_det.per_cell;
+        cache_n = cur_det.n;
+    }
+    cs.slot_last = plan.slot_cur;
+    cs.cols = plan.cols; cs.rows = plan.rows;
+    cs.t_last = plan.timestamp;
+}
+
+void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id) {
+    std::unique_ptr<std::lock_guard<std::mutex>> lck;
+    if (cam_id < mtx_feeds.size()) lck.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id]));
+    MonoPlan plan;
+    FrameSource fs;
+    fs.host = img.data; fs.cols = img.cols; fs.rows = img.rows; fs.step = img.step;
+    if (mono_begin(timestamp, fs, cam_id, plan) != FT_OK) return;
+    const ft_lk_params prm = lk_params();
+    if (be->build_pyramid(1, &plan.stream, &plan.slot_cur, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+
+    const int cells = Grider_FAST::cells_for(img.cols, img.rows, grid_x, grid_y);
+    const int kmax = per_cell_max();
+    Detection last_det, cur_det;
+    std::vector<ft_keypoint> last_buf;
+    std::vector<int> last_cells;
+    int last_n = 0, cur_n = 0;
+    const bool have_last = cams[cam_id].slot_last >= 0 && !pts_last[cam_id].empty();
+    if (speculative_detect) {
+        if (have_last && cache_valid) {
+            last_det.valid = true; last_det.per_cell = cache_per_cell; last_det.cells = (int)cache_cell_counts.size();
+            last_det.kps = cache_kps.data(); last_det.n = cache_n; last_det.cell_counts = cache_cell_counts.data();
+        }
+    } else if (have_last) {
+        const int need = mono_features_needed(plan);
+        if (need > 1 && cells > 0) {         // detector on the previous frame, only when needed (TrackKLT.cpp:271-275)
+            const int per_cell = need / (grid_x * grid_y) + 1;
+            last_buf.resize((size_t)cells * per_cell); last_cells.resize(cells);
+            if (be->fast_grid_async(1, &plan.stream, &plan.slot_last, threshold, grid_x, grid_y, per_cell, last_buf.data(),
+                                    (int)last_buf.size(), &last_n, last_cells.data()) == FT_OK && be->sync() == FT_OK) {
+                last_det.valid = true; last_det.per_cell = per_cell; last_det.cells = cells;
+                last_det.kps = last_buf.data(); last_det.n = last_n; last_det.cell_counts = last_cells.data();
+            }
+        }
+    }
+    ft_lk_job job;
+    mono_prepare(plan, last_det, job);
+    bool want_cur_det = (speculative_detect || plan.first) && cells > 0;
+    if (want_cur_det) {
+        det_buf.resize((size_t)cells * kmax); det_cells.resize(cells);
+        want_cur_det = be->fast_grid_async(1, &plan.stream, &plan.slot_cur, threshold, grid_x, grid_y, kmax, det_buf.data(),
+                                           (int)det_buf.size(), &cur_n, det_cells.data()) == FT_OK;
+    }
+    if (plan.run_lk && be->lk_track_async(1, &job, &prm) != FT_OK) plan.reset = true;
+    if (be->sync() != FT_OK) plan.reset = true;
+    if (want_cur_det) {
+        cur_det.valid = true; cur_det.per_cell = kmax; cur_det.cells = cells;
+        cur_det.kps = det_buf.data(); cur_det.n = cur_n; cur_det.cell_counts = det_cells.data();
+    }
+    mono_finish(plan, cur_det);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stereo path
+// ---------------------------------------------------------------------------------------------------------------
+
+void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
+    const ft_lk_params prm = lk_params();
+    struct Buf { std::vector<float> p0, p1, err; std::vector<uint8_t> st; };
+    std::vector<Buf> bufs(jobs.size());
+    std::vector<ft_lk_job> lk;
+    std::vector<size_t> lk_owner;
+    for (size_t j = 0; j < jobs.size(); j++) {
+        MatchJob& M = jobs[j];
+        M.mask_out->clear();
+        const size_t n = M.kpts0->size();
+        if (n == 0 || M.kpts1->size() != n) continue;          // TrackKLT.cpp:377-381: mask stays empty
+        if (n < 10) { M.mask_out->assign(n, 0); continue; }    // TrackKLT.cpp:392-396
+        Buf& B = bufs[j];
+        B.p0.resize(2 * n); B.p1.resize(2 * n); B.err.resize(n); B.st.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            B.p0[2 * i] = (*M.kpts0)[i].pt.x; B.p0[2 * i + 1] = (*M.kpts0)[i].pt.y;
+            B.p1[2 * i] = (*M.kpts1)[i].pt.x; B.p1[2 * i + 1] = (*M.kpts1)[i].pt.y;
+        }
+        ft_lk_job J;
+        memset(&J, 0, sizeof(J));
+        J.stream_prev = M.img0.stream; J.slot_prev = M.img0.slot;
+        J.stream_next = M.img1.stream; J.slot_next = M.img1.slot;
+        J.n = (int)n; J.prev_xy = B.p0.data(); J.next_xy = B.p1.data(); J.status = B.st.data(); J.err = B.err.data();
+        J.H = M.H;
+        lk.push_back(J);
+        lk_owner.push_back(j);
+    }
+    if (lk.empty()) return;
+    if (be->lk_track_async((int)lk.size(), lk.data(), &prm) != FT_OK || be->sync() != FT_OK) return;
+    for (size_t q = 0; q < lk.size(); q++) {
+        MatchJob& M = jobs[lk_owner[q]];
+        Buf& B = bufs[lk_owner[q]];
+        const size_t n = M.kpts0->size();
+        // outlier rejection by fundamental-matrix RANSAC (TrackKLT.cpp:405-424) is not part of this build: LK status only
+        M.mask_out->assign(B.st.begin(), B.st.end());
+        for (size_t i = 0; i < n; i++) (*M.kpts1)[i].pt = Point2f(B.p1[2 * i], B.p1[2 * i + 1]);   // TrackKLT.cpp:427-430
+    }
+}
+
+void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
+                                        std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1) {
+    Occupancy grid0(img0.cols, img0.rows, min_px_dist), grid1(img1.cols, img1.rows, min_px_dist);
+    filter_by_occupancy(grid0, pts0, ids0);
+    filter_by_occupancy(grid1, pts1, ids1);
+
+    // LEFT: extract, then try to find the new points in the right image (TrackKLT.cpp:266-341)
+    const int num_featsneeded_0 = num_features - (int)pts0.size();
+    if (num_featsneeded_0 > 1) {
+        std::vector<KeyPoint> pts0_ext;
+        Grider_FAST::perform_griding(img0, pts0_ext, num_featsneeded_0, grid_x, grid_y, threshold, true);
+        std::vector<KeyPoint> kpts0_new;
+        for (const KeyPoint& kpt : pts0_ext) {
+            if (grid0.taken(kpt.pt)) continue;
+            kpts0_new.push_back(kpt);
+            grid0.take(kpt.pt);
+        }
+        if (!kpts0_new.empty()) {
+            // same-pixel initial guess in the right image (TrackKLT.cpp:290-295)
+            const size_t n = kpts0_new.size();
+            std::vector<float> p0(2 * n), p1(2 * n), err(n);
+            std::vector<uint8_t> mask(n);
+            for (size_t i = 0; i < n; i++) { p0[2 * i] = kpts0_new[i].pt.x; p0[2 * i + 1] = kpts0_new[i].pt.y; }
+            p1 = p0;
+            ft_lk_job J;
+            memset(&J, 0, sizeof(J));
+            J.stream_prev = img0.stream; J.slot_prev = img0.slot; J.stream_next = img1.stream; J.slot_next = img1.slot;
+            J.n = (int)n; J.prev_xy = p0.data(); J.next_xy = p1.data(); J.status = mask.data(); J.err = err.data();
+            ft_lk_params prm = lk_params();
+            prm.flags = FT_LK_USE_INITIAL_FLOW;   // the stereo association has no backward pass in the reference
+            const bool ok = be->lk_track_async(1, &J, &prm) == FT_OK && be->sync() == FT_OK;
+            for (size_t i = 0; ok && i < n; i++) {
+                const Point2f a(p0[2 * i], p0[2 * i + 1]), b(p1[2 * i], p1[2 * i + 1]);
+                const bool oob0 = a.x < 0 || a.y < 0 || a.x >= img0.cols || a.y >= img0.rows;
+                const bool oob1 = b.x < 0 || b.y < 0 || b.x >= img1.cols || b.y >= img1.rows;
+                if (!oob0 && mask[i] == 1 && !oob1 && !grid1.taken(b)) {   // stereo feature (TrackKLT.cpp:318-328)
+                    KeyPoint k0 = kpts0_new[i], k1 = kpts0_new[i];
+                    k0.pt = a; k1.pt = b;
+                    pts0.push_back(k0); pts1.push_back(k1);
+                    const size_t id = ++currid;
+                    ids0.push_back(id); ids1.push_back(id);
+                } else if (!oob0) {                                        // left-only feature (TrackKLT.cpp:329-337)
+                    KeyPoint k0 = kpts0_new[i];
+                    k0.pt = a;
+                    pts0.push_back(k0);
+                    ids0.push_back(++currid);
+                }
+            }
+        }
+    }
+
+    // RIGHT: extract right-only features (TrackKLT.cpp:343-365)
+    const int num_featsneeded_1 = num_features - (int)pts1.size();
+    if (num_featsneeded_1 > 1) {
+        std::vector<KeyPoint> pts1_ext;
+        Grider_FAST::perform_griding(img1, pts1_ext, num_featsneeded_1, grid_x, grid_y, threshold, true);
+        for (const KeyPoint& kpt : pts1_ext) {
+            if (grid1.taken(kpt.pt)) continue;
+            pts1.push_back(kpt);
+            ids1.push_back(++currid);
+            grid1.take(kpt.pt);
+        }
+    }
+}
+
+void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Image8& img_rightin, size_t cam_id_left, size_t cam_id_right) {
+    std::unique_ptr<std::lock_guard<std::mutex>> lck1, lck2;
+    if (cam_id_left < mtx_feeds.size()) lck1.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id_left]));
+    if (cam_id_right < mtx_feeds.size() && cam_id_right != cam_id_left) lck2.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id_right]));
+
+    CamState& cl = cams[cam_id_left];
+    CamState& cr = cams[cam_id_right];
+    const int sl = stream0 + (int)cam_id_left, sr = stream0 + (int)cam_id_right;
+    const int cur_l = cl.slot_last == 0 ? 1 : 0, cur_r = cr.slot_last == 0 ? 1 : 0;
+
+    // ingest both frames and build both pyramids (with gradients) in one batched launch per level (TrackKLT.cpp:45-58)
+    if (be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
+    if (be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
+    const int streams[2] = {sl, sr}, slots[2] = {cur_l, cur_r};
+    if (img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows) {
+        if (be->build_pyramid(2, streams, slots, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+    } else {
+        if (be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+        if (be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+    }
+    const DeviceImage cur_left{be, sl, cur_l, img_leftin.cols, img_leftin.rows};
+    const DeviceImage cur_right{be, sr, cur_r, img_rightin.cols, img_rightin.rows};
+    auto roll = [&]() {
+        cl.slot_last = cur_l; cl.cols = img_leftin.cols; cl.rows = img_leftin.rows; cl.t_last = timestamp;
+        cr.slot_last = cur_r; cr.cols = img_rightin.cols; cr.rows = img_rightin.rows; cr.t_last = timestamp;
+    };
+    auto& ptsL = pts_last[cam_id_left];
+    auto& ptsR = pts_last[cam_id_right];
+    auto& idsL = ids_last[cam_id_left];
+    auto& idsR = ids_last[cam_id_right];
+
+    // first call, or tracking was lost: just extract (TrackKLT.cpp:63-72)
+    if (ptsL.empty() || ptsR.empty() || cl.slot_last < 0 || cr.slot_last < 0) {
+        perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR);
+        roll();
+        return;
+    }
+
+    // top the previous pair up (TrackKLT.cpp:76-78)
+    const DeviceImage last_left{be, sl, cl.slot_last, cl.cols, cl.rows};
+    const DeviceImage last_right{be, sr, cr.slot_last, cr.cols, cr.rows};
+    perform_detection_stereo(last_left, last_right, ptsL, ptsR, idsL, idsR);
+
+    // temporal tracking of both cameras in one launch (TrackKLT.cpp:86-98)
+    std::vector<uint8_t> mask_ll, mask_rr;
+    std::vector<KeyPoint> pts_left_new = ptsL, pts_right_new = ptsR;
+    float Hl[9], Hr[9];
+    Mat3f R0, R1;
+    bool seeded = false;
+    if (use_gyro_seed && camera_k.count(cam_id_left) && camera_k.count(cam_id_right) &&
+        propagator->integrate_by_msckfVio(cl.t_last, timestamp, R0, R1, false) > 0) {
+        const auto& Kl = camera_k.at(cam_id_left);
+        const auto& Kr = camera_k.at(cam_id_right);
+        const float K4l[4] = {(float)Kl[0], (float)Kl[1], (float)Kl[2], (float)Kl[3]};
+        const float K4r[4] = {(float)Kr[0], (float)Kr[1], (float)Kr[2], (float)Kr[3]};
+        be->homography(K4l, R0.data(), Hl);
+        be->homography(K4r, R1.data(), Hr);
+        seeded = true;
+    }
+    std::vector<MatchJob> jobs(2);
+    jobs[0] = MatchJob{last_left, cur_left, &ptsL, &pts_left_new, cam_id_left, cam_id_left, &mask_ll, seeded ? Hl : nullptr};
+    jobs[1] = MatchJob{last_right, cur_right, &ptsR, &pts_right_new, cam_id_right, cam_id_right, &mask_rr, seeded ? Hr : nullptr};
+    perform_matching(jobs);
+
+    // not enough points: reset and re-detect next time (TrackKLT.cpp:118-129)
+    if (mask_ll.empty() || mask_rr.empty()) {
+        roll();
+        ptsL.clear(); ptsR.clear(); idsL.clear(); idsR.clear();
+        printf("[KLT-EXTRACTOR]: Failed to get enough points to do RANSAC, resetting.....\n");
+        return;
+    }
+
+    // merge: stereo tracks need both temporal tracks to succeed (TrackKLT.cpp:132-181)
+    std::vector<KeyPoint> good_left, good_right;
+    std::vector<size_t> good_ids_left, good_ids_right;
+    std::unordered_map<size_t, size_t> right_index;
+    for (size_t n = idsR.size(); n-- > 0;) right_index[idsR[n]] = n;   // first occurrence wins, as the linear search does
+    std::unordered_map<size_t, char> right_added;
+    for (size_t i = 0; i < pts_left_new.size(); i++) {
+        if (pts_left_new[i].pt.x < 0 || pts_left_new[i].pt.y < 0) continue;
+        auto it = right_index.find(idsL[i]);
+        const bool found_right = it != right_index.end();
+        const size_t index_right = found_right ? it->second : 0;
+        if (mask_ll[i] && found_right && mask_rr[index_right]) {
+            if (pts_right_new[index_right].pt.x < 0 || pts_right_new[index_right].pt.y < 0) continue;
+            good_left.push_back(pts_left_new[i]);
+            good_right.push_back(pts_right_new[index_right]);
+            good_ids_left.push_back(idsL[i]);
+            good_ids_right.push_back(idsR[index_right]);
+            right_added[idsR[index_right]] = 1;
+        } else if (mask_ll[i]) {
+            good_left.push_back(pts_left_new[i]);
+            good_ids_left.push_back(idsL[i]);
+        }
+    }
+    for (size_t i = 0; i < pts_right_new.size(); i++) {
+        if (pts_right_new[i].pt.x < 0 || pts_right_new[i].pt.y < 0) continue;
+        if (mask_rr[i] && !right_added.count(idsR[i])) {
+            good_right.push_back(pts_right_new[i]);
+            good_ids_right.push_back(idsR[i]);
+            right_added[idsR[i]] = 1;
+        }
+    }
+
+    // feature database (TrackKLT.cpp:187-198)
+    if (camera_k.count(cam_id_left) && camera_k.count(cam_id_right)) {
+        for (size_t i = 0; i < good_left.size(); i++) {
+            const Point2f n = undistort_point(good_left[i].pt, cam_id_left);
+            database->update_feature(good_ids_left[i], timestamp, cam_id_left, good_left[i].pt.x, good_left[i].pt.y, n.x, n.y);
+        }
+        for (size_t i = 0; i < good_right.size(); i++) {
+            const Point2f n = undistort_point(good_right[i].pt, cam_id_right);
+            database->update_feature(good_ids_right[i], timestamp, cam_id_right, good_right[i].pt.x, good_right[i].pt.y, n.x, n.y);
+        }
+    }
+
+    // move forward in time (TrackKLT.cpp:201-208)
+    roll();
+    ptsL.swap(good_left); ptsR.swap(good_right);
+    idsL.swap(good_ids_left); idsR.swap(good_ids_right);
+}
+
+}  // namespace feature_tracker

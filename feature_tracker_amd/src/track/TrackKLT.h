@@ -1,0 +1,178 @@
+// KLT visual front-end (call surface of src/track/TrackKLT.h:40-127) driving the batched device kernels.
+//
+// Differences from the reference that follow from the device design, none of which change results:
+//  * images live in a ring of two device pyramid slots per camera instead of host cv::Mat vectors;
+//  * the two pyramids of a stereo pair, and the two temporal LK calls, are one batched launch each instead of
+//    two host threads (src/track/TrackKLT.cpp:51-58, :91-98);
+//  * the id merge uses a hash map instead of the O(N^2) search (src/track/TrackKLT.cpp:136-166);
+//  * with speculative_detect the detector runs on every new frame right after its pyramid, so that topping the
+//    previous frame up at the next call (src/track/TrackKLT.cpp:76-78) needs no extra device round trip; the
+//    per-cell lists are ranked, so truncating them to the count actually needed gives what the reference computes.
+// The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) is not part of this build yet:
+// mask_out is the LK status.
+#pragma once
+#include <vector>
+
+#include "../FeatureTrackerOptions.h"
+#include "Grider_FAST.h"
+#include "TrackBase.h"
+
+namespace feature_tracker {
+
+// a frame to ingest: host pixels (copied through pinned staging) or a device-resident frame
+struct FrameSource {
+    const uint8_t* host = nullptr;
+    const void* dev = nullptr;
+    int cols = 0, rows = 0;
+    size_t step = 0;
+};
+
+// ranked per-cell detector output for one image, as returned by one batched fast_grid call
+struct Detection {
+    bool valid = false;
+    int per_cell = 0;                 // keep count the detector was launched with
+    int cells = 0;
+    const ft_keypoint* kps = nullptr; // cells concatenated in index order
+    int n = 0;
+    const int* cell_counts = nullptr; // NMS survivors per cell before truncation
+};
+
+class TrackKLT : public TrackBase {
+public:
+    // reference constructor (src/track/TrackKLT.h:58-59) plus the backend and the first backend stream this tracker
+    // uses: camera cam_id lives in backend stream stream_base + cam_id
+    explicit TrackKLT(FrontendBackend* backend, int numfeats, int numaruco, int fast_threshold, int gridx, int gridy, int minpxdist,
+                      int stream_base = 0)
+        : TrackBase(numfeats, numaruco), be(backend), stream0(stream_base), threshold(fast_threshold), grid_x(gridx), grid_y(gridy),
+          min_px_dist(minpxdist) {}
+
+    TrackKLT(FrontendBackend* backend, const FeatureTrackerOptions& o, int numaruco = 0, int stream_base = 0)
+        : TrackBase(o.num_pts, numaruco), be(backend), stream0(stream_base), threshold(o.fast_threshold), grid_x(o.grid_x),
+          grid_y(o.grid_y), min_px_dist(o.min_px_dist), pyr_levels(o.pyr_levels), win_size(o.win_size), lk_max_iter(o.lk_max_iter),
+          lk_eps(o.lk_eps), lk_min_eig(o.lk_min_eig), use_gyro_seed(o.use_gyro_seed), forward_backward(o.forward_backward),
+          fb_thresh(o.fb_thresh), speculative_detect(o.speculative_detect) {}
+
+    void feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) override;
+
+    // single-camera variant of feed_stereo (the fork's upstream has one; the benchmark streams are monocular)
+    void feed_monocular(double timestamp, const Image8& img, size_t cam_id);
+
+    // ---- staged monocular interface: lets a driver run many independent trackers through shared batched launches ----
+    struct MonoPlan {
+        size_t cam = 0;
+        double timestamp = 0;
+        int stream = 0, slot_cur = 0, slot_last = 0;
+        int cols = 0, rows = 0;
+        bool first = false;        // no previous points: detect on the current frame and return
+        bool run_lk = false;
+        bool reset = false;        // too few points: reference resets and re-detects next time
+        std::vector<float> prev_xy, next_xy, err;
+        std::vector<uint8_t> status;
+        float H[9];
+        bool use_H = false;
+    };
+    // 1. choose slots and enqueue the frame copy
+    int mono_begin(double timestamp, const FrameSource& frame, size_t cam_id, MonoPlan& plan);
+    // 2a. (non-speculative only) how many features the previous frame lacks; > 1 means it wants a detection on slot_last
+    int mono_features_needed(const MonoPlan& plan);
+    // 2b. top the previous frame up from `last_det` (may be invalid = nothing to add) and lay out the LK job
+    void mono_prepare(MonoPlan& plan, const Detection& last_det, ft_lk_job& job_out);
+    // 3. after the LK results are in: bookkeeping; cur_det = detection of the current frame (first-frame case / cache)
+    void mono_finish(MonoPlan& plan, const Detection& cur_det);
+
+    ft_lk_params lk_params() const;
+    int per_cell_max() const { return num_features / (grid_x * grid_y) + 1; }
+    int grid_cols() const { return grid_x; }
+    int grid_rows() const { return grid_y; }
+    int fast_threshold() const { return threshold; }
+    int max_level() const { return pyr_levels; }
+    int window() const { return win_size; }
+    bool speculative() const { return speculative_detect; }
+    // detector output of the last frame cached by mono_finish (speculative mode)
+    const std::vector<ft_keypoint>& cached_detection(int& per_cell, std::vector<int>& cell_counts) const {
+        per_cell = cache_valid ? cache_per_cell : 0;
+        cell_counts = cache_cell_counts;
+        return cache_kps;
+    }
+    size_t tracked_last(size_t cam_id) const {
+        auto it = pts_last.find(cam_id);
+        return it == pts_last.end() ? 0 : it->second.size();
+    }
+
+protected:
+    // src/track/TrackKLT.cpp:223-368
+    void perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
+                                  std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1);
+    // monocular top-off: occupancy filter, then new points from a ranked detection
+    void perform_detection_monocular(int cols, int rows, const Detection& det, std::vector<KeyPoint>& pts0, std::vector<size_t>& ids0);
+    // src/track/TrackKLT.cpp:371-432 for one or two (img0 -> img1) pairs in one launch
+    struct MatchJob {
+        DeviceImage img0, img1;
+        std::vector<KeyPoint>* kpts0;
+        std::vector<KeyPoint>* kpts1;
+        size_t id0, id1;
+        std::vector<uint8_t>* mask_out;
+        const float* H;
+    };
+    void perform_matching(std::vector<MatchJob>& jobs);
+
+    // occupancy grid of (rows/min_px_dist+2) x (cols/min_px_dist+2) cells, first come wins (TrackKLT.cpp:230-263)
+    struct Occupancy {
+        int gw = 0, gh = 0, dist = 1;
+        std::vector<uint8_t> cell;
+        Occupancy(int cols, int rows, int min_px_dist) : gw(cols / min_px_dist + 2), gh(rows / min_px_dist + 2), dist(min_px_dist), cell((size_t)gw * gh, 0) {}
+        // (int)(coord / min_px_dist): float division, truncation toward zero
+        bool index(const Point2f& p, size_t& idx) const {
+            const int cx = (int)(p.x / dist), cy = (int)(p.y / dist);
+            if (cx < 0 || cy < 0 || cx >= gw || cy >= gh) return false;   // the reference would index out of bounds here
+            idx = (size_t)cy * gw + cx;
+            return true;
+        }
+        bool taken(const Point2f& p) const { size_t i; return index(p, i) ? cell[i] != 0 : true; }
+        void take(const Point2f& p) { size_t i; if (index(p, i)) cell[i] = 1; }
+    };
+    static void filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, std::vector<size_t>& ids);
+    static std::vector<KeyPoint> select_from_detection(const Detection& det, int num_needed, int grid_x, int grid_y);
+    bool gyro_homography(size_t cam_id, double t_last, double t_cur, float* H);
+
+    FrontendBackend* be;
+    int stream0;
+
+    // FAST grid detector parameters
+    int threshold;
+    int grid_x;
+    int grid_y;
+    int min_px_dist;
+
+    // LK parameters (reference: pyr_levels = 3, win_size = 15x15)
+    int pyr_levels = 3;
+    int win_size = 15;
+    int lk_max_iter = 15;
+    double lk_eps = 0.01;
+    double lk_min_eig = 1e-4;
+    bool use_gyro_seed = false;
+    bool forward_backward = false;
+    float fb_thresh = 1.0f;
+    bool speculative_detect = true;
+
+    // per camera: device slot holding the last pyramid (-1 = none), its size and timestamp
+    struct CamState {
+        int slot_last = -1;
+        int cols = 0, rows = 0;
+        double t_last = 0;
+    };
+    std::map<size_t, CamState> cams;
+
+    // cached ranked detection of the last monocular frame
+    std::vector<ft_keypoint> cache_kps;
+    std::vector<int> cache_cell_counts;
+    int cache_per_cell = 0;
+    int cache_n = 0;
+    bool cache_valid = false;
+
+    // scratch for feed_monocular's own one-stream batch
+    std::vector<ft_keypoint> det_buf;
+    std::vector<int> det_cells;
+};
+
+}  // namespace feature_tracker

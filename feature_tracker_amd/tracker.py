@@ -1,0 +1,200 @@
+"""ctypes binding of include/ft_tracker.h: the host tracker layer (TrackKLT / TrackKLTBatch) on the gfx950 device
+library.  ``lib_path`` exists so that the test-suite can drive the identical wrapper over its CPU checker build."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libft_tracker.so")
+
+
+class ftk_options(C.Structure):
+    _fields_ = [("num_pts", C.c_int), ("fast_threshold", C.c_int), ("grid_x", C.c_int), ("grid_y", C.c_int),
+                ("min_px_dist", C.c_int), ("pyr_levels", C.c_int), ("win_size", C.c_int), ("lk_max_iter", C.c_int),
+                ("lk_eps", C.c_double), ("lk_min_eig", C.c_double), ("use_gyro_seed", C.c_int), ("forward_backward", C.c_int),
+                ("fb_thresh", C.c_float), ("speculative_detect", C.c_int)]
+
+
+SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "ftk_tracker_set_calibration",
+           "ftk_tracker_feed_imu", "ftk_tracker_feed_stereo", "ftk_tracker_feed_monocular", "ftk_tracker_get_points",
+           "ftk_tracker_database_size", "ftk_tracker_get_track", "ftk_batch_create", "ftk_batch_destroy",
+           "ftk_batch_set_calibration", "ftk_batch_feed_imu", "ftk_batch_feed", "ftk_batch_get_points",
+           "ftk_batch_device_ctx", "ftk_backend_name"]
+
+_libs = {}
+
+
+def load_library(lib_path=None):
+    path = lib_path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it first (__graft_entry__.build()); there is no fallback")
+    L = C.CDLL(path)
+    vp, dp = C.c_void_p, C.POINTER(C.c_double)
+    L.ftk_default_options.argtypes = [C.POINTER(ftk_options)]
+    L.ftk_default_options.restype = None
+    L.ftk_tracker_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ftk_options), C.c_int, C.c_int]
+    L.ftk_tracker_destroy.argtypes = [vp]
+    L.ftk_tracker_destroy.restype = None
+    L.ftk_tracker_set_calibration.argtypes = [vp, C.c_int, dp, dp]
+    L.ftk_tracker_feed_imu.argtypes = [vp, C.c_double, dp, dp]
+    L.ftk_tracker_feed_stereo.argtypes = [vp, C.c_double, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int]
+    L.ftk_tracker_feed_monocular.argtypes = [vp, C.c_double, vp, C.c_int, C.c_int, C.c_size_t, C.c_int]
+    L.ftk_tracker_get_points.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.ftk_tracker_database_size.argtypes = [vp]
+    L.ftk_tracker_get_track.argtypes = [vp, C.c_uint64, C.c_int, vp, vp, C.c_int]
+    L.ftk_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ftk_options), C.c_int, C.c_int, C.c_int]
+    L.ftk_batch_destroy.argtypes = [vp]
+    L.ftk_batch_destroy.restype = None
+    L.ftk_batch_set_calibration.argtypes = [vp, C.c_int, dp, dp]
+    L.ftk_batch_feed_imu.argtypes = [vp, C.c_int, C.c_double, dp, dp]
+    L.ftk_batch_feed.argtypes = [vp, dp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.ftk_batch_get_points.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.ftk_batch_device_ctx.argtypes = [vp]
+    L.ftk_batch_device_ctx.restype = vp
+    L.ftk_backend_name.argtypes = []
+    L.ftk_backend_name.restype = C.c_char_p
+    _libs[path] = L
+    return L
+
+
+def make_options(lib, **kw):
+    o = ftk_options()
+    lib.ftk_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown tracker option {k}")
+        setattr(o, k, v)
+    return o
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class _Base:
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with code {rc}")
+
+
+class Tracker(_Base):
+    """One TrackKLT with cameras 0 and 1 (reference driver usage: src/test_tracking.cpp:229-231,:148,:207)."""
+
+    def __init__(self, max_width, max_height, device=0, lib_path=None, **options):
+        self.lib = load_library(lib_path)
+        self.opts = make_options(self.lib, **options)
+        self._h = C.c_void_p()
+        self._check(self.lib.ftk_tracker_create(C.byref(self._h), device, C.byref(self.opts), max_width, max_height), "ftk_tracker_create")
+
+    def close(self):
+        if self._h:
+            self.lib.ftk_tracker_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_calibration(self, calib8, T_cam_imu=None):
+        k = np.ascontiguousarray(calib8, dtype=np.float64).reshape(-1, 8)
+        T = None if T_cam_imu is None else np.ascontiguousarray(T_cam_imu, dtype=np.float64).reshape(-1, 16)
+        self._check(self.lib.ftk_tracker_set_calibration(self._h, k.shape[0], _dp(k), None if T is None else _dp(T)), "set_calibration")
+
+    def feed_imu(self, t, am, wm):
+        a, w = np.ascontiguousarray(am, dtype=np.float64), np.ascontiguousarray(wm, dtype=np.float64)
+        self._check(self.lib.ftk_tracker_feed_imu(self._h, t, _dp(a), _dp(w)), "feed_imu")
+
+    def feed_stereo(self, t, left, right, cam_left=0, cam_right=1):
+        left, right = np.ascontiguousarray(left, dtype=np.uint8), np.ascontiguousarray(right, dtype=np.uint8)
+        h, w = left.shape
+        self._check(self.lib.ftk_tracker_feed_stereo(self._h, t, left.ctypes.data, right.ctypes.data, w, h, left.strides[0], cam_left, cam_right), "feed_stereo")
+
+    def feed_monocular(self, t, img, cam=0):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        self._check(self.lib.ftk_tracker_feed_monocular(self._h, t, img.ctypes.data, w, h, img.strides[0], cam), "feed_monocular")
+
+    def points(self, cam=0):
+        n = self.lib.ftk_tracker_get_points(self._h, cam, None, None, 0)
+        xy, ids = np.zeros((n, 2), dtype=np.float32), np.zeros(n, dtype=np.uint64)
+        if n:
+            self.lib.ftk_tracker_get_points(self._h, cam, xy.ctypes.data, ids.ctypes.data, n)
+        return xy, ids
+
+    def database_size(self):
+        return self.lib.ftk_tracker_database_size(self._h)
+
+    def track(self, feat_id, cam=0):
+        n = self.lib.ftk_tracker_get_track(self._h, int(feat_id), cam, None, None, 0)
+        uv, ts = np.zeros((n, 4), dtype=np.float32), np.zeros(n, dtype=np.float64)
+        if n > 0:
+            self.lib.ftk_tracker_get_track(self._h, int(feat_id), cam, uv.ctypes.data, ts.ctypes.data, n)
+        return uv, ts
+
+
+class BatchTracker(_Base):
+    """n independent monocular streams through shared batched launches (TrackKLTBatch)."""
+
+    def __init__(self, n_streams, max_width, max_height, device=0, lib_path=None, **options):
+        self.lib = load_library(lib_path)
+        self.opts = make_options(self.lib, **options)
+        self.n = n_streams
+        self._h = C.c_void_p()
+        self._check(self.lib.ftk_batch_create(C.byref(self._h), device, C.byref(self.opts), n_streams, max_width, max_height), "ftk_batch_create")
+        self._ptrs = (C.c_void_p * n_streams)()
+        self._ts = np.zeros(n_streams, dtype=np.float64)
+
+    def close(self):
+        if self._h:
+            self.lib.ftk_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_calibration(self, stream, calib8, T_cam_imu=None):
+        k = np.ascontiguousarray(calib8, dtype=np.float64).reshape(8)
+        T = None if T_cam_imu is None else np.ascontiguousarray(T_cam_imu, dtype=np.float64).reshape(16)
+        self._check(self.lib.ftk_batch_set_calibration(self._h, stream, _dp(k), None if T is None else _dp(T)), "batch_set_calibration")
+
+    def feed_imu(self, stream, t, am, wm):
+        a, w = np.ascontiguousarray(am, dtype=np.float64), np.ascontiguousarray(wm, dtype=np.float64)
+        self._check(self.lib.ftk_batch_feed_imu(self._h, stream, t, _dp(a), _dp(w)), "batch_feed_imu")
+
+    def feed_host(self, timestamps, frames):
+        """frames: sequence of n (h, w) uint8 arrays."""
+        keep = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        h, w = keep[0].shape
+        for i, f in enumerate(keep):
+            self._ptrs[i] = f.ctypes.data
+        return self._feed(timestamps, 0, w, h, keep[0].strides[0])
+
+    def feed_device(self, timestamps, dev_ptrs, w, h, stride):
+        """dev_ptrs: n device addresses of frames resident in HBM."""
+        for i, p in enumerate(dev_ptrs):
+            self._ptrs[i] = int(p)
+        return self._feed(timestamps, 1, w, h, stride)
+
+    def _feed(self, timestamps, on_device, w, h, stride):
+        self._ts[:] = timestamps
+        tracked, attempted = C.c_longlong(), C.c_longlong()
+        self._check(self.lib.ftk_batch_feed(self._h, _dp(self._ts), self._ptrs, on_device, w, h, stride, C.byref(tracked), C.byref(attempted)), "ftk_batch_feed")
+        return tracked.value, attempted.value
+
+    def points(self, stream):
+        n = self.lib.ftk_batch_get_points(self._h, stream, None, None, 0)
+        xy, ids = np.zeros((n, 2), dtype=np.float32), np.zeros(n, dtype=np.uint64)
+        if n:
+            self.lib.ftk_batch_get_points(self._h, stream, xy.ctypes.data, ids.ctypes.data, n)
+        return xy, ids
+
+    def device_ctx(self):
+        return self.lib.ftk_batch_device_ctx(self._h)

@@ -520,20 +520,21 @@ void fto_fast_score_map(const uint8_t* img, int w, int h, size_t stride, int thr
         }
 }
 
-// Grider_FAST::perform_griding (Grider_FAST.h:76-132)
-int fto_grid_fast(const uint8_t* img, int w, int h, size_t stride, int num_features, int grid_x, int grid_y,
-                  int threshold, int nonmax, int tie_mode, int n_threads, fto_keypoint* out, int cap) {
-    if (grid_x <= 0 || grid_y <= 0) return -1;
+// Grider_FAST::perform_griding (Grider_FAST.h:76-132) with the per-cell keep count given directly
+int fto_grid_fast_cells(const uint8_t* img, int w, int h, size_t stride, int per_cell, int grid_x, int grid_y, int threshold,
+                        int nonmax, int tie_mode, int n_threads, fto_keypoint* out, int cap, int* cell_counts) {
+    if (grid_x <= 0 || grid_y <= 0 || per_cell < 0) return -1;
     const int size_x = w / grid_x, size_y = h / grid_y;                  // :80-81
     if (size_x <= 0 || size_y <= 0) return -1;
-    const int per_cell = num_features / (grid_x * grid_y) + 1;          // :88
     const int ct_cols = w / size_x, ct_rows = h / size_y;               // :91-92
     std::vector<std::vector<fto_keypoint>> collection((size_t)ct_cols * ct_rows);
+    std::vector<int> found((size_t)ct_cols * ct_rows, 0);
     auto cell = [&](int r) {
         const int x = r % ct_cols * size_x, y = r / ct_cols * size_y;   // :98-99
         if (x + size_x > w || y + size_y > h) return;                   // :102-103
         std::vector<fto_keypoint> pts;
         fast_detect(img + (size_t)y * stride + x, size_x, size_y, stride, threshold, nonmax != 0, pts);   // :110
+        found[r] = (int)pts.size();
         if (tie_mode == 1) {
             std::sort(pts.begin(), pts.end(), [](fto_keypoint a, fto_keypoint b) { return a.response > b.response; });   // :113
         } else {
@@ -561,7 +562,15 @@ int fto_grid_fast(const uint8_t* img, int w, int h, size_t stride, int num_featu
     int n = 0;
     for (auto& c : collection)                                           // :128-130
         for (auto& k : c) { if (n < cap) out[n] = k; n++; }
+    if (cell_counts) for (int r = 0; r < ncell; r++) cell_counts[r] = found[r];
     return std::min(n, cap);
+}
+
+int fto_grid_fast(const uint8_t* img, int w, int h, size_t stride, int num_features, int grid_x, int grid_y,
+                  int threshold, int nonmax, int tie_mode, int n_threads, fto_keypoint* out, int cap) {
+    if (grid_x <= 0 || grid_y <= 0) return -1;
+    const int per_cell = num_features / (grid_x * grid_y) + 1;          // :88
+    return fto_grid_fast_cells(img, w, h, stride, per_cell, grid_x, grid_y, threshold, nonmax, tie_mode, n_threads, out, cap, nullptr);
 }
 
 // mean-gyro rotation (TrackPropagator.h:107-153)

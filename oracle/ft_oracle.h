@@ -81,6 +81,11 @@ void fto_fast_score_map(const uint8_t* img, int w, int h, size_t stride, int thr
 int fto_grid_fast(const uint8_t* img, int w, int h, size_t stride, int num_features, int grid_x, int grid_y,
                   int threshold, int nonmax, int tie_mode, int n_threads, fto_keypoint* out, int cap);
 
+/* Same with the per-cell keep count given directly; cell_counts (optional, one int per cell) receives the number of
+ * corners FAST found in each cell before truncation. */
+int fto_grid_fast_cells(const uint8_t* img, int w, int h, size_t stride, int per_cell, int grid_x, int grid_y, int threshold,
+                        int nonmax, int tie_mode, int n_threads, fto_keypoint* out, int cap, int* cell_counts);
+
 /* Mean-gyro rotation between two frames (TrackPropagator.h:107-153 with the window end fixed to use the
  * sample under the end iterator): R_p_c = Rodrigues(R_cam_imu_T * mean_gyro * dt)^T, row-major float[9].
  * imu_t: n timestamps; gyro: n*3; R_imu_to_cam: row-major 3x3 (the rotation block of T_cam_imu). */

@@ -1,0 +1,148 @@
+"""Host-logic tests that need no GPU: the tracker orchestration (TrackKLT / TrackKLTBatch) run on the CPU checker
+backend, the C-ABI libraries' exported symbols, and the synthetic sequence generator."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from feature_tracker_amd import device, synth, tracker
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC = os.path.join(ROOT, "oracle", "libft_oracle_tracker.so")
+
+
+@pytest.fixture(scope="module")
+def seq():
+    O.lib()   # makes sure the oracle libraries are built
+    return synth.Sequence(752, 480, 20, stream_id=0)
+
+
+def _run(seq, n_frames=20, **opts):
+    b = tracker.BatchTracker(1, seq.w, seq.h, lib_path=ORC, **opts)
+    b.set_calibration(0, seq.calib8, seq.T_cam_imu)
+    for t, g, a in zip(seq.imu_t, seq.gyro, seq.accel):
+        b.feed_imu(0, t, a, g)
+    hist = []
+    for i in range(n_frames):
+        tr, at = b.feed_host([seq.timestamps[i]], [seq.frames[i]])
+        xy, ids = b.points(0)
+        hist.append((tr, at, xy.copy(), ids.copy()))
+    return hist
+
+
+def test_device_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(device.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "ft_device.h")).read()
+    for name in device.SYMBOLS:
+        assert name + "(" in hdr, f"{name} not declared in ft_device.h"
+        assert hasattr(lib, name), f"{name} not exported"
+    import re
+    declared = set(re.findall(r"\b(ft_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(device.SYMBOLS)
+
+
+def test_tracker_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ft_tracker.h")).read()
+    import re
+    declared = set(re.findall(r"\b(ftk_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(tracker.SYMBOLS)
+    for path in (tracker.LIB_PATH, ORC):
+        lib = ctypes.CDLL(path)
+        for name in tracker.SYMBOLS:
+            assert hasattr(lib, name), f"{name} not exported by {path}"
+    assert ctypes.CDLL(ORC).ftk_backend_name is not None
+
+
+def test_product_libraries_do_not_contain_the_oracle():
+    for path in (device.LIB_PATH, tracker.LIB_PATH):
+        lib = ctypes.CDLL(path)
+        assert not hasattr(lib, "fto_lk_track") and not hasattr(lib, "fto_pyramid_build")
+    lib = tracker.load_library()
+    assert lib.ftk_backend_name() == b"hip-gfx950"
+
+
+def test_sequence_generator_is_deterministic_and_bounded(seq):
+    again = synth.Sequence(752, 480, 5, stream_id=0, threads=3)
+    assert np.array_equal(again.frames, seq.frames[:5])          # same seed, any thread count
+    other = synth.Sequence(752, 480, 2, stream_id=1)
+    assert not np.array_equal(other.frames[0], seq.frames[0])
+    assert np.abs(np.diff(seq.center, axis=0)).max() <= 6.0 + 1e-9
+    assert np.rad2deg(np.abs(np.diff(seq.theta)).max()) <= 0.5 + 1e-9
+    assert 60 < seq.frames.mean() < 200 and seq.frames.std() > 20
+
+
+def test_end_to_end_tracking_keeps_ids_and_counts(seq):
+    hist = _run(seq, win_size=21, use_gyro_seed=1)
+    assert hist[0][0] == 0 and len(hist[0][2]) >= 100            # first frame only detects
+    for tr, at, xy, ids in hist[1:]:
+        assert at >= 100 and tr >= 0.9 * at                      # >= 90 % of the attempted features survive
+        assert len(set(ids.tolist())) == len(ids)                # ids unique
+    # a feature keeps its id: ids present in the last frame that existed at frame 1 trace a smooth path
+    first_ids = set(hist[1][3].tolist())
+    survivors = [i for i in hist[-1][3].tolist() if i in first_ids]
+    assert len(survivors) >= 40
+    for fid in survivors[:10]:
+        path = np.array([h[2][list(h[3]).index(fid)] for h in hist[1:]])
+        assert np.abs(np.diff(path, axis=0)).max() < 12.0
+
+
+def test_speculative_detection_equals_on_demand_detection(seq):
+    a = _run(seq, 12, win_size=15, speculative_detect=1)
+    b = _run(seq, 12, win_size=15, speculative_detect=0)
+    for (tr_a, at_a, xy_a, id_a), (tr_b, at_b, xy_b, id_b) in zip(a, b):
+        assert tr_a == tr_b and at_a == at_b and np.array_equal(id_a, id_b) and np.array_equal(xy_a, xy_b)
+
+
+def test_gyro_seed_reduces_iterations_not_results_much(seq):
+    plain = _run(seq, 10, win_size=21, use_gyro_seed=0)
+    seeded = _run(seq, 10, win_size=21, use_gyro_seed=1)
+    assert abs(plain[-1][0] - seeded[-1][0]) <= 10
+    common = set(plain[5][3].tolist()) & set(seeded[5][3].tolist())
+    assert len(common) > 80
+    pa = {i: p for i, p in zip(plain[5][3].tolist(), plain[5][2])}
+    pb = {i: p for i, p in zip(seeded[5][3].tolist(), seeded[5][2])}
+    d = np.array([np.abs(pa[i] - pb[i]).max() for i in common])
+    assert np.median(d) < 0.05
+
+
+def test_forward_backward_option_is_stricter(seq):
+    plain = _run(seq, 6, win_size=21)
+    fb = _run(seq, 6, win_size=21, forward_backward=1, fb_thresh=0.5)
+    assert fb[-1][0] <= plain[-1][0]
+
+
+def test_stereo_feed_tracks_both_cameras_and_fills_database(seq):
+    t = tracker.Tracker(seq.w, seq.h, lib_path=ORC, win_size=15)
+    t.set_calibration(np.stack([seq.calib8, seq.calib8]), np.stack([seq.T_cam_imu, seq.T_cam_imu]))
+    # right camera = left image shifted by 4 px (a fronto-parallel plane): stereo tracks must be found
+    for i in range(8):
+        left = seq.frames[i]
+        right = np.roll(left, -4, axis=1)
+        t.feed_stereo(seq.timestamps[i], left, right)
+    xl, il = t.points(0)
+    xr, ir = t.points(1)
+    assert len(xl) > 80 and len(xr) > 80
+    both = set(il.tolist()) & set(ir.tolist())
+    assert len(both) > 50                                           # stereo features share one id
+    li = {i: p for i, p in zip(il.tolist(), xl)}
+    ri = {i: p for i, p in zip(ir.tolist(), xr)}
+    disp = np.array([li[i][0] - ri[i][0] for i in both])
+    assert abs(np.median(disp) - 4.0) < 0.2
+    assert t.database_size() >= len(both)
+    fid = next(iter(both))
+    uv, ts = t.track(fid, 0)
+    assert len(ts) >= 1 and np.all(np.diff(ts) > 0)
+    # normalized coordinates = (u - cx) / fx with zero distortion
+    assert np.allclose(uv[:, 2], (uv[:, 0] - seq.calib8[2]) / seq.calib8[0], atol=1e-5)
+
+
+def test_mono_tracker_class_matches_batch_of_one(seq):
+    t = tracker.Tracker(seq.w, seq.h, lib_path=ORC, win_size=21)
+    t.set_calibration(np.stack([seq.calib8, seq.calib8]))
+    hist = _run(seq, 8, win_size=21)
+    for i in range(8):
+        t.feed_monocular(seq.timestamps[i], seq.frames[i], 0)
+        xy, ids = t.points(0)
+        assert np.array_equal(ids, hist[i][3]) and np.array_equal(xy, hist[i][2])
