@@ -60,6 +60,22 @@ SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device"
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process cannot both own the GPU, so
+    when torch is installed its copy is mapped first: this library's libamdhip64.so.7 dependency then resolves to it
+    (same SONAME) and a later ``import torch`` finds its copy already loaded."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Load libft_device.so; raise if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
@@ -68,6 +84,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (__graft_entry__.build()); "
                           "there is no CPU fallback for the device path")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     lib.ft_ctx_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ft_limits)]

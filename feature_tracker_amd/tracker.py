@@ -31,6 +31,9 @@ def load_library(lib_path=None):
         return _libs[path]
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it first (__graft_entry__.build()); there is no fallback")
+    if lib_path is None:
+        from . import device
+        device.load_library()      # maps the HIP runtime and libft_device.so first
     L = C.CDLL(path)
     vp, dp = C.c_void_p, C.POINTER(C.c_double)
     L.ftk_default_options.argtypes = [C.POINTER(ftk_options)]
