@@ -60,8 +60,8 @@ def make_sequences(wl, n_frames, rank, threads):
     return [synth.Sequence(wl["w"], wl["h"], n_frames, stream_id=rank * 1000 + s, threads=threads) for s in range(wl["streams"])]
 
 
-def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0):
-    b = tracker_mod.BatchTracker(wl["streams"], wl["w"], wl["h"], device=device, lib_path=lib_path, **wl["opts"])
+def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0, n_groups=0):
+    b = tracker_mod.BatchTracker(wl["streams"], wl["w"], wl["h"], device=device, lib_path=lib_path, n_groups=n_groups, **wl["opts"])
     for s, q in enumerate(seqs):
         b.set_calibration(s, q.calib8, q.T_cam_imu)
         for t, g, a in zip(q.imu_t, q.gyro, q.accel):
@@ -144,6 +144,7 @@ def main():
     stamps = [[q.timestamps[i] for q in seqs] for i in range(n_frames)]
 
     b = setup_tracker(tracker, wl, seqs, device=local_rank)
+    groups = b.groups()
 
     def barrier():
         torch.cuda.synchronize()
@@ -154,21 +155,28 @@ def main():
     for i in range(W + 1):
         b.feed_device(stamps[i], ptrs[i], w, h, w)
     barrier()
+    b.stage_times(reset=True)
     t0 = time.perf_counter()
     tracked = attempted = 0
     for i in range(W + 1, W + 1 + K):
-        tr, at = b.feed_device(stamps[i], ptrs[i], w, h, w)
+        # software-pipelined feed: the last stream group's frame completes during the next call (or in flush below)
+        tr, at = b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
         tracked += tr
         attempted += at
+    tr, at = b.flush()
+    tracked += tr
+    attempted += at
     barrier()
     dt = time.perf_counter() - t0
+    host_stages = b.stage_times()
 
     # ---- per-kernel device time over the same K steps (HIP events on the tracker's own queue) ----
+    # One stream group (one device context, one queue) so that a kernel's events bracket that kernel alone.
     lib = ftdev.load_library()
     import ctypes as C
-    ctx = C.c_void_p(b.device_ctx())
-    b2 = setup_tracker(tracker, wl, seqs, device=local_rank)
-    ctx2 = C.c_void_p(b2.device_ctx())
+    del b
+    b2 = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=1)
+    ctx2 = C.c_void_p(b2.group_ctx(0))
     for i in range(W + 1):
         b2.feed_device(stamps[i], ptrs[i], w, h, w)
     lib.ft_profile(ctx2, 1)
@@ -177,7 +185,6 @@ def main():
     kt = ftdev.ft_kernel_time()
     lib.ft_kernel_times(ctx2, C.byref(kt), 1)
     lib.ft_profile(ctx2, 0)
-    del ctx
 
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -219,6 +226,8 @@ def main():
             "frames_per_sec": world * S * K / dt_max,
             "roofline": roofline,
             "kernels": per_kernel,
+            "host_stage_ms": host_stages,
+            "stream_groups": groups,
             "setup": {"sequence_generation_s": t_gen},
         }
         if not args.no_latency:

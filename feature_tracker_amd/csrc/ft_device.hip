@@ -73,7 +73,6 @@ struct ft_ctx {
     PendingLK lk_pending;
 
     // FAST scratch
-    uint8_t* score = nullptr; uint32_t score_pitch = 0; uint64_t score_img_bytes = 0;
     uint32_t* cand = nullptr; size_t cand_entries_per_img = 0;
     int* cand_count = nullptr;          // [n_streams][max_grid_cells]
     ft_keypoint* kp_dev = nullptr;      // [n_streams][max_grid_cells][max_per_cell]
@@ -325,10 +324,6 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lk_out_dev = (uint8_t*)p;
 
     // FAST scratch
-    c->score_pitch = (uint32_t)align_up((size_t)lim->max_width, 256);
-    c->score_img_bytes = (uint64_t)c->score_pitch * lim->max_height;
-    if (hipMalloc(&p, c->score_img_bytes * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
-    c->score = (uint8_t*)p;
     c->cand_entries_per_img = ((size_t)lim->max_width + 2 * 64) * ((size_t)lim->max_height + 2 * 64) / 4 + (size_t)lim->max_grid_cells;
     if (hipMalloc(&p, sizeof(uint32_t) * c->cand_entries_per_img * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
     c->cand = (uint32_t*)p;
@@ -368,7 +363,6 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_in_dev) (void)hipFree(c->lk_in_dev);
     if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
-    if (c->score) (void)hipFree(c->score);
     if (c->cand) (void)hipFree(c->cand);
     if (c->cand_count) (void)hipFree(c->cand_count);
     if (c->kp_dev) (void)hipFree(c->kp_dev);
@@ -399,16 +393,31 @@ int ft_upload(ft_ctx* c, int stream, int slot, const uint8_t* host, int w, int h
     return FT_OK;
 }
 
-int ft_set_frame_device(ft_ctx* c, int stream, int slot, const void* dev, int w, int h, size_t stride) {
-    if (!c || !dev || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
-    const int si = slot_index(c, stream, slot);
-    if (si < 0) return FT_E_INVALID;
+int ft_set_frames_device(ft_ctx* c, int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride) {
+    if (!c || n < 1 || n > FT_MAX_BATCH || !streams || !slots || !dev || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
     if (w > c->lim.max_width || h > c->lim.max_height) return FT_E_LIMIT;
+    ImgList L;
+    L.n = n;
+    for (int i = 0; i < n; i++) {
+        const int si = slot_index(c, streams[i], slots[i]);
+        if (si < 0 || !dev[i]) return FT_E_INVALID;
+        L.idx[i] = si;
+    }
     FT_HIP(c, hipSetDevice(c->device));
-    uint8_t* dst = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[0].img_off;
-    FT_HIP(c, hipMemcpy2DAsync(dst, c->arena.lv[0].img_pitch, dev, stride, (size_t)w, (size_t)h, hipMemcpyDeviceToDevice, c->q));
-    c->slots[si] = SlotState{w, h, 1, 0};
+    for (int first = 0; first < n; first += FRAME_PTRS) {
+        const int m = std::min(FRAME_PTRS, n - first);
+        FramePtrs F;
+        for (int i = 0; i < m; i++) F.p[i] = static_cast<const uint8_t*>(dev[first + i]);
+        dim3 grid(((w + 15) / 16 + 255) / 256, h, m);
+        hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, c->q, c->arena, L, F, first, w, h, (uint64_t)stride);
+    }
+    FT_HIP(c, hipGetLastError());
+    for (int i = 0; i < n; i++) c->slots[L.idx[i]] = SlotState{w, h, 1, 0};
     return FT_OK;
+}
+
+int ft_set_frame_device(ft_ctx* c, int stream, int slot, const void* dev, int w, int h, size_t stride) {
+    return ft_set_frames_device(c, 1, &stream, &slot, &dev, w, h, stride);
 }
 
 int ft_build_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
@@ -594,9 +603,8 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     FT_HIP(c, hipMemsetAsync(c->cand_count, 0, sizeof(int) * (size_t)n * cells, c->q));
     EventPair ep;
     prof_begin(c, 2, ep);
-    dim3 grid((w + 63) / 64, (h + 3) / 4, n);
-    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, c->q, c->arena, L, G, c->score, c->score_pitch, c->score_img_bytes);
-    hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, c->q, G, c->score, c->score_pitch, c->score_img_bytes, c->cand, c->cand_count);
+    dim3 grid((w + FD_TX - 1) / FD_TX, (h + FD_TY - 1) / FD_TY, n);
+    hipLaunchKernelGGL(fast_detect_kernel, grid, dim3(256), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
     hipLaunchKernelGGL(fast_topk_kernel, dim3(n * cells), dim3(256), 0, c->q, G, c->cand, c->cand_count, c->kp_dev, c->kp_count_dev);
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());

@@ -5,10 +5,10 @@
 // in the 3-pixel band inside each cell border and NMS never sees a neighbouring cell's score: the score map is
 // therefore zero outside the cell insets, and a single image-wide 3x3 strict-maximum test equals per-cell NMS.
 //
-//   fast_score_kernel : u8 image -> u8 score map (0 = not a corner), HBM-bound (reads level 0 once).
-//   fast_nms_kernel   : strict 3x3 maxima -> per-cell candidate lists (unordered, one atomic per survivor).
-//   fast_topk_kernel  : one workgroup per cell extracts the first `per_cell` candidates in the total order
-//                       (score desc, y asc, x asc).
+//   fast_detect_kernel : u8 image -> per-cell candidate lists (score + position keys, unordered); reads level 0
+//                        once, keeps pixels and scores in LDS, one global atomic per NMS survivor.
+//   fast_topk_kernel   : one workgroup per cell extracts the first `per_cell` candidates in the total order
+//                        (score desc, y asc, x asc).
 #pragma once
 #include "ft_common.hpp"
 
@@ -25,56 +25,22 @@ struct FastGrid {
 
 // strength = max over the 16 arcs of 9 contiguous circle pixels of min(d) (darker arc) or min(-d) (brighter arc),
 // d[k] = v - p[k].  The pixel is a corner iff strength > threshold; its OpenCV score is strength - 1.
+// Sliding 9-wide min/max as two rounds of 3-input min/max (v_min3 / v_max3).
 __device__ inline int fast_strength(const int (&d)[16]) {
-    int mn2[16], mx2[16];
+    int mn3[16], mx3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
     int best = -256;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = max(best, max(mn9, -mx9));
+        const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+        const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
+        best = max(max(best, mn9), -mx9);
     }
     return best;
-}
-
-__global__ void __launch_bounds__(256) fast_score_kernel(ArenaDesc A, ImgList L, FastGrid G, uint8_t* __restrict__ score, uint32_t sc_pitch, uint64_t sc_img_bytes) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= G.w || y >= G.h) return;
-    const int slot = L.idx[blockIdx.z];
-    uint8_t* sc = score + (uint64_t)blockIdx.z * sc_img_bytes + (size_t)y * sc_pitch + x;
-    // position inside the cell; pixels right of / below the last full cell belong to no cell
-    const int cxi = x / G.size_x, cyi = y / G.size_y;
-    const int lx = x - cxi * G.size_x, ly = y - cyi * G.size_y;
-    uint8_t out = 0;
-    if (cxi < G.ct_cols && cyi < G.ct_rows && lx >= 3 && lx < G.size_x - 3 && ly >= 3 && ly < G.size_y - 3) {
-        const uint8_t* __restrict__ img = level_img(A, slot, 0);
-        const uint32_t pitch = A.lv[0].img_pitch;
-        const uint8_t* p = img + (size_t)y * pitch + x;
-        const int v = p[0];
-        const int t = G.threshold;
-        // quick reject: a 9-arc contains one pixel of every opposite pair
-        const int p0 = p[3 * (int)pitch], p8 = p[-3 * (int)pitch], p4 = p[3], p12 = p[-3];
-        const int lo = v - t, hi = v + t;
-        const bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
-        const bool bright = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
-        if (dark || bright) {
-            int d[16];
-            const int ip = (int)pitch;
-            d[0] = v - p0;               d[1] = v - p[3 * ip + 1];   d[2] = v - p[2 * ip + 2];   d[3] = v - p[ip + 3];
-            d[4] = v - p4;               d[5] = v - p[-ip + 3];      d[6] = v - p[-2 * ip + 2];  d[7] = v - p[-3 * ip + 1];
-            d[8] = v - p8;               d[9] = v - p[-3 * ip - 1];  d[10] = v - p[-2 * ip - 2]; d[11] = v - p[-ip - 3];
-            d[12] = v - p12;             d[13] = v - p[ip - 3];      d[14] = v - p[2 * ip - 2];  d[15] = v - p[3 * ip - 1];
-            const int s = fast_strength(d);
-            if (s > t) out = (uint8_t)(s - 1);
-        }
-    }
-    *sc = out;
 }
 
 // candidate key: score in the top byte, then inverted cell-local y, then inverted cell-local x, so that a larger
@@ -83,21 +49,95 @@ __device__ inline uint32_t fast_key(int score, int ly, int lx) {
     return ((uint32_t)score << 24) | ((uint32_t)(4095 - ly) << 12) | (uint32_t)(4095 - lx);
 }
 
-__global__ void __launch_bounds__(256) fast_nms_kernel(FastGrid G, const uint8_t* __restrict__ score, uint32_t sc_pitch, uint64_t sc_img_bytes,
-                                                      uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 1 || y < 1 || x >= G.w - 1 || y >= G.h - 1) return;
-    const uint8_t* sc = score + (uint64_t)blockIdx.z * sc_img_bytes + (size_t)y * sc_pitch + x;
-    const int s = sc[0];
-    if (s == 0) return;   // a corner's score is >= threshold; threshold 0 corners with score 0 never pass strict NMS
-    const int ip = (int)sc_pitch;
-    if (s > sc[-1] && s > sc[1] && s > sc[-ip - 1] && s > sc[-ip] && s > sc[-ip + 1] && s > sc[ip - 1] && s > sc[ip] && s > sc[ip + 1]) {
-        const int cxi = x / G.size_x, cyi = y / G.size_y;
-        const int cell = cyi * G.ct_cols + cxi;
-        const int gcell = blockIdx.z * (G.ct_cols * G.ct_rows) + cell;
-        const int slot = atomicAdd(&cand_count[gcell], 1);
-        if (slot < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + slot] = fast_key(s, y - cyi * G.size_y, x - cxi * G.size_x);
+constexpr int FD_TX = 64, FD_TY = 16;            // output tile
+constexpr int FD_PW = FD_TX + 8, FD_PH = FD_TY + 8;   // pixel tile: 4-pixel apron (3 for the circle + 1 for NMS)
+constexpr int FD_SW = FD_TX + 2, FD_SH = FD_TY + 2;   // score tile: 1-pixel apron
+constexpr int FD_SPITCH = 68;
+
+// Fused detector: one 256-thread workgroup owns a 64x16 tile.  The pixel tile is staged in LDS once; a cheap
+// compass test compacts the candidates; the exact corner strength is evaluated only for those (dense lanes);
+// strict 3x3 maxima of the LDS score tile go straight to the per-cell candidate lists.  No score map in HBM.
+__global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L, FastGrid G, uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
+    __shared__ __attribute__((aligned(16))) uint8_t pix[FD_PH * FD_PW];
+    __shared__ uint8_t sc[FD_SH * FD_SPITCH];
+    __shared__ uint16_t list[FD_SW * FD_SH];
+    __shared__ uint8_t col_ok[FD_SW], row_ok[FD_SH];   // column / row lies in the inset of some cell
+    __shared__ int list_n;
+    const int t = threadIdx.x;
+    const int slot = L.idx[blockIdx.z];
+    const int X0 = blockIdx.x * FD_TX, Y0 = blockIdx.y * FD_TY;
+    const uint8_t* __restrict__ img = level_img(A, slot, 0);
+    const uint32_t pitch = A.lv[0].img_pitch;
+
+    // ---- stage pixels: 24 rows x 18 dwords; coordinates are clamped (only insets are ever evaluated, and an
+    //      inset pixel's circle lies inside the image) ----
+    for (int i = t; i < FD_PH * (FD_PW / 4); i += 256) {
+        const int rr = i / (FD_PW / 4), d = i - rr * (FD_PW / 4);
+        const int gy = min(max(Y0 - 4 + rr, 0), G.h - 1);
+        const int gxd = min(max((X0 - 4) / 4 + d, 0), (int)(pitch / 4) - 1);
+        reinterpret_cast<uint32_t*>(pix)[rr * (FD_PW / 4) + d] = reinterpret_cast<const uint32_t*>(img + (size_t)gy * pitch)[gxd];
+    }
+    for (int i = t; i < FD_SH * FD_SPITCH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    if (t == 0) list_n = 0;
+    // cell membership is separable: one division per column and per row of the tile instead of two per pixel
+    if (t < FD_SW) {
+        const int gx = X0 - 1 + t;
+        const int cxi = gx >= 0 ? gx / G.size_x : 0, lx = gx - cxi * G.size_x;
+        col_ok[t] = (gx >= 0 && gx < G.w && cxi < G.ct_cols && lx >= 3 && lx < G.size_x - 3) ? 1 : 0;
+    } else if (t >= 128 && t < 128 + FD_SH) {
+        const int gy = Y0 - 1 + (t - 128);
+        const int cyi = gy >= 0 ? gy / G.size_y : 0, ly = gy - cyi * G.size_y;
+        row_ok[t - 128] = (gy >= 0 && gy < G.h && cyi < G.ct_rows && ly >= 3 && ly < G.size_y - 3) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // ---- compass test on the 66x18 score region: a 9-arc holds one pixel of every opposite pair ----
+    const int thr = G.threshold;
+    for (int i = t; i < FD_SW * FD_SH; i += 256) {
+        const int sj = i / FD_SW, si = i - sj * FD_SW;
+        if (!(col_ok[si] & row_ok[sj])) continue;
+        const uint8_t* p = &pix[(sj + 3) * FD_PW + si + 3];
+        const int v = p[0], lo = v - thr, hi = v + thr;
+        const int p0 = p[3 * FD_PW], p8 = p[-3 * FD_PW], p4 = p[3], p12 = p[-3];
+        const bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
+        const bool bright = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
+        if (dark || bright) list[atomicAdd(&list_n, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    // ---- exact strength for the compacted candidates ----
+    const int n_list = list_n;
+    for (int c = t; c < n_list; c += 256) {
+        const int i = list[c];
+        const int sj = i / FD_SW, si = i - sj * FD_SW;
+        const uint8_t* p = &pix[(sj + 3) * FD_PW + si + 3];
+        const int v = p[0];
+        int d[16];
+        d[0] = v - p[3 * FD_PW];      d[1] = v - p[3 * FD_PW + 1];   d[2] = v - p[2 * FD_PW + 2];   d[3] = v - p[FD_PW + 3];
+        d[4] = v - p[3];              d[5] = v - p[-FD_PW + 3];      d[6] = v - p[-2 * FD_PW + 2];  d[7] = v - p[-3 * FD_PW + 1];
+        d[8] = v - p[-3 * FD_PW];     d[9] = v - p[-3 * FD_PW - 1];  d[10] = v - p[-2 * FD_PW - 2]; d[11] = v - p[-FD_PW - 3];
+        d[12] = v - p[-3];            d[13] = v - p[FD_PW - 3];      d[14] = v - p[2 * FD_PW - 2];  d[15] = v - p[3 * FD_PW - 1];
+        const int s = fast_strength(d);
+        if (s > thr) sc[sj * FD_SPITCH + si] = (uint8_t)(s - 1);
+    }
+    __syncthreads();
+
+    // ---- strict 3x3 maxima -> per-cell candidate lists ----
+    const int cells = G.ct_cols * G.ct_rows;
+#pragma unroll
+    for (int r = 0; r < FD_TY / 4; r++) {
+        const int ox = t & 63, oy = (t >> 6) + 4 * r;
+        const uint8_t* q = &sc[(oy + 1) * FD_SPITCH + ox + 1];
+        const int s = q[0];
+        if (s == 0) continue;   // a score of 0 can never be a strict maximum
+        if (s > q[-1] && s > q[1] && s > q[-FD_SPITCH - 1] && s > q[-FD_SPITCH] && s > q[-FD_SPITCH + 1] &&
+            s > q[FD_SPITCH - 1] && s > q[FD_SPITCH] && s > q[FD_SPITCH + 1]) {
+            const int gx = X0 + ox, gy = Y0 + oy;
+            const int cxi = gx / G.size_x, cyi = gy / G.size_y;
+            const int gcell = blockIdx.z * cells + cyi * G.ct_cols + cxi;
+            const int at = atomicAdd(&cand_count[gcell], 1);
+            if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
+        }
     }
 }
 

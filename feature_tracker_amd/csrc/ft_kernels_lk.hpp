@@ -3,10 +3,14 @@
 // Replaces cv::calcOpticalFlowPyrLK / LKTrackerInvoker as called at src/track/TrackKLT.cpp:306 and :402.
 //
 // Lane layout: the win_w x win_h window is cut into row segments of SEGLEN pixels; lane = row * SEGS + segment.
-// Each lane keeps its SEGLEN template samples (I*32, Ix, Iy) in registers for the whole level, so every Newton
-// iteration only fetches the two target-image rows the lane needs and one wave-wide reduction of (b1, b2).
-// All sums are exact integers: lanes accumulate in int32, the wave reduction runs on 16-bit halves with DPP
-// adds (no LDS traffic), and the total is rounded to float once.
+//  * Template: each lane samples its SEGLEN pixels of I (x32) and of the Scharr gradients once per level and keeps
+//    them in registers.
+//  * Target: the part of J the window can reach (window + a margin of LK_MARGIN pixels on every side) is staged in
+//    LDS once per level with aligned dword loads (REFLECT_101 applied while staging); every Newton iteration then
+//    reads two LDS rows per lane, so the dependent chain position -> pixels -> (b1,b2) -> position never waits on
+//    HBM.  A window that walks out of the staged region re-stages it around the current position.
+//  * Sums are exact integers: lanes accumulate in int32, the wave reduction runs on 16-bit halves with DPP adds
+//    (no LDS traffic), and the total is rounded to float once, so results do not depend on the reduction order.
 #pragma once
 #include "ft_common.hpp"
 
@@ -39,6 +43,10 @@ struct LKArgs {
     double min_eig;
 };
 
+constexpr int LK_MARGIN = 5;                                     // staged margin around the target window, pixels
+constexpr int LK_RW_DWORDS = (32 + 1 + 2 * LK_MARGIN + 3 + 3) / 4;   // widest staged row: 12 dwords
+constexpr int LK_RH_MAX = 32 + 1 + 2 * LK_MARGIN;                // tallest staged region: 43 rows
+
 // ---- wave-wide exact integer sum (result uniform in all lanes) ----
 __device__ inline int wave_sum_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
@@ -70,36 +78,121 @@ __device__ inline BilinW bilin_weights(float a, float b) {
     return r;
 }
 
-// SEGLEN+1 pixels of image row y starting at column x; REFLECT_101 outside the image
+typedef short lk_v2s __attribute__((ext_vector_type(2)));
+__device__ inline int dot2_acc(uint32_t pair, uint32_t wpair, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, pair), __builtin_bit_cast(lk_v2s, wpair), acc, false);
+}
+
+struct __attribute__((packed)) U32Unaligned { uint32_t v; };
+
+// ---- template loads: SEGLEN+1 pixels of row y from column x ----
 template <int SEGLEN>
-__device__ inline void load_row_u8(const uint8_t* __restrict__ img, uint32_t pitch, int w, int h, int x, int y, int (&out)[SEGLEN + 1]) {
-    const uint8_t* row = img + (size_t)reflect101(y, h) * pitch;
-    if (x >= 0 && x + SEGLEN < w) {
+__device__ inline void load_row_u8(const uint8_t* __restrict__ img, uint32_t pitch, int w, int h, int x, int y, bool interior, int (&out)[SEGLEN + 1]) {
+    if (interior) {   // wave-uniform: the whole window lies inside the image
+        const uint8_t* p = img + (size_t)y * pitch + x;
 #pragma unroll
-        for (int k = 0; k <= SEGLEN; k++) out[k] = row[x + k];
+        for (int q = 0; q < SEGLEN / 4; q++) {
+            const uint32_t v = reinterpret_cast<const U32Unaligned*>(p + 4 * q)->v;
+            out[4 * q] = v & 0xff; out[4 * q + 1] = (v >> 8) & 0xff; out[4 * q + 2] = (v >> 16) & 0xff; out[4 * q + 3] = v >> 24;
+        }
+        out[SEGLEN] = p[SEGLEN];
     } else {
+        const uint8_t* row = img + (size_t)reflect101(y, h) * pitch;
 #pragma unroll
         for (int k = 0; k <= SEGLEN; k++) out[k] = row[reflect101(x + k, w)];
     }
 }
 
-// SEGLEN+1 gradient samples of row y starting at column x; zero outside the image
+// SEGLEN+1 gradient samples of row y from column x; zero outside the image
 template <int SEGLEN>
-__device__ inline void load_row_grad(const uint8_t* __restrict__ grad, uint32_t pitch, int w, int h, int x, int y, int (&gx)[SEGLEN + 1], int (&gy)[SEGLEN + 1]) {
-    const bool row_in = (y >= 0 && y < h);
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(grad + (size_t)(row_in ? y : 0) * pitch);
+__device__ inline void load_row_grad(const uint8_t* __restrict__ grad, uint32_t pitch, int w, int h, int x, int y, bool interior, int (&gx)[SEGLEN + 1], int (&gy)[SEGLEN + 1]) {
+    if (interior) {
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(grad + (size_t)y * pitch) + x;
 #pragma unroll
-    for (int k = 0; k <= SEGLEN; k++) {
-        const int xx = x + k;
-        uint32_t v = 0;
-        if (row_in && xx >= 0 && xx < w) v = row[xx];
-        gx[k] = (int)(int16_t)(v & 0xffff);
-        gy[k] = (int)v >> 16;
+        for (int k = 0; k <= SEGLEN; k++) {
+            const uint32_t v = row[k];
+            gx[k] = (int)(int16_t)(v & 0xffff);
+            gy[k] = (int)v >> 16;
+        }
+    } else {
+        const bool row_in = (y >= 0 && y < h);
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(grad + (size_t)(row_in ? y : 0) * pitch);
+#pragma unroll
+        for (int k = 0; k <= SEGLEN; k++) {
+            const int xx = x + k;
+            uint32_t v = 0;
+            if (row_in && xx >= 0 && xx < w) v = row[xx];
+            gx[k] = (int)(int16_t)(v & 0xffff);
+            gy[k] = (int)v >> 16;
+        }
+    }
+}
+
+// ---- target region in LDS ----
+struct JRegion {
+    int rx0, ry0;     // image coordinates of the region origin (rx0 is a multiple of 4)
+    int rwd, rh;      // size in dwords x rows
+};
+
+// stage the region that a window at integer origin (inx, iny) can reach within LK_MARGIN pixels
+__device__ inline JRegion stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
+                                       int inx, int iny, int ext_w, int win_h, int lane) {
+    JRegion R;
+    R.rx0 = ((inx - LK_MARGIN) >> 2) << 2;
+    R.ry0 = iny - LK_MARGIN;
+    R.rwd = (inx + ext_w + 1 + LK_MARGIN - R.rx0 + 3) >> 2;    // <= LK_RW_DWORDS
+    R.rh = win_h + 1 + 2 * LK_MARGIN;                          // <= LK_RH_MAX
+    const int c = lane & 15, rr = lane >> 4;
+    if (c < R.rwd) {
+        const int gx = R.rx0 + 4 * c;
+        const bool col_in = gx >= 0 && gx + 3 < w;
+        for (int row = rr; row < R.rh; row += 4) {
+            const uint8_t* src = img + (size_t)reflect101(R.ry0 + row, h) * pitch;
+            uint32_t v;
+            if (col_in) {
+                v = *reinterpret_cast<const uint32_t*>(src + gx);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect101(gx + k, w)] << (8 * k);
+            }
+            lds[row * LK_RW_DWORDS + c] = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes are done (one wave per workgroup)
+    __builtin_amdgcn_wave_barrier();
+    return R;
+}
+
+__device__ inline bool region_holds(const JRegion& R, int inx, int iny, int ext_w, int win_h) {
+    return inx >= R.rx0 && inx + ext_w + 1 <= R.rx0 + 4 * R.rwd && iny >= R.ry0 && iny + win_h + 1 <= R.ry0 + R.rh;
+}
+
+// (J[k], J[k+1]) pairs, k = 0..SEGLEN-1, of one staged row as packed 16-bit pairs for v_dot2
+template <int SEGLEN>
+__device__ inline void read_row_pairs(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&pairs)[SEGLEN]) {
+    constexpr int NDW = SEGLEN / 4 + 1;
+    const uint32_t* p = lds + row * LK_RW_DWORDS + (byte_off >> 2);
+    const uint32_t sh = byte_off & 3;
+    uint32_t d[NDW + 1];
+#pragma unroll
+    for (int q = 0; q < NDW; q++) d[q] = p[q];
+    d[NDW] = 0;
+    uint32_t e[NDW];   // bytes realigned to the window column
+#pragma unroll
+    for (int q = 0; q < NDW; q++) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+#pragma unroll
+    for (int k = 0; k < SEGLEN; k++) {
+        const int q = k >> 2, b = k & 3;
+        // byte b and byte b+1 of the 8-byte string {e[q+1], e[q]} into the low halves of the two 16-bit lanes
+        if (b < 3) pairs[k] = __builtin_amdgcn_perm(0u, e[q], 0x0c000c00u | (uint32_t)b | ((uint32_t)(b + 1) << 16));
+        else pairs[k] = __builtin_amdgcn_perm(e[q + 1], e[q], 0x0c040c03u);
     }
 }
 
 template <int SEGLEN>
 __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
+    __shared__ uint32_t jlds[LK_RH_MAX * LK_RW_DWORDS + 4];   // + slack: row reads are dword-granular
     const int pt = blockIdx.x;
     const int lane = threadIdx.x;
     const LKJobDev* job = a.jobs + a.pt_job[pt];
@@ -107,6 +200,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     const int r = lane / a.segs, s = lane - r * a.segs;
     const int x0 = s * SEGLEN;
     const bool row_ok = r < wh;
+    const int rc = row_ok ? r : wh - 1;          // lanes below the window reuse its last row (results masked)
+    const int ext_w = a.segs * SEGLEN;           // columns the lanes touch: [0, ext_w]
     const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
 
     // forward: template = prev pyramid at prev_xy, target = next pyramid, guess from next_xy / H / prev
@@ -134,19 +229,14 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         use_init = true;
     }
 
-    int lw[FT_MAX_LEVELS], lh[FT_MAX_LEVELS];
-    lw[0] = job->w0; lh[0] = job->h0;
-#pragma unroll
-    for (int l = 1; l < FT_MAX_LEVELS; l++) { lw[l] = half_up(lw[l - 1]); lh[l] = half_up(lh[l - 1]); }
-
     float outx = gx0, outy = gy0;   // nextPts[i]
     int st = 1;
     float errv = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
 
     for (int level = a.max_level; level >= 0; level--) {
-        int w = lw[0], h = lh[0];
-#pragma unroll
-        for (int l = 1; l < FT_MAX_LEVELS; l++) if (l == level) { w = lw[l]; h = lh[l]; }
+        int w = job->w0, h = job->h0;
+        for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
         const float scale = (float)(1. / (1 << level));
         float px = tx * scale, py = ty * scale;
         float nx, ny;
@@ -160,7 +250,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         int n_iter = -1;
 
         px -= half_x; py -= half_y;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        // positions are identical in all lanes: keep the integer parts in scalar registers
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
         if (ipx < -ww || ipx >= w || ipy < -wh || ipy >= h) {
             if (level == 0) { st = 0; errv = 0.f; }
             if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
@@ -168,18 +259,21 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         }
 
         // ---- template: bilinear samples of I (x32) and of the Scharr gradients ----
-        int Iw[SEGLEN], Gx[SEGLEN], Gy[SEGLEN];
+        int Iw[SEGLEN];
+        int Gx[SEGLEN], Gy[SEGLEN];
+        const uint32_t ipitch = a.A.lv[level].img_pitch, gpitch = a.A.lv[level].grad_pitch;
+        float A11, A12, A22;
         {
             const BilinW bw = bilin_weights(px - ipx, py - ipy);
             const uint8_t* imgI = level_img(a.A, img_I, level);
             const uint8_t* grdI = level_grad(a.A, img_I, level);
-            const uint32_t ipitch = a.A.lv[level].img_pitch, gpitch = a.A.lv[level].grad_pitch;
+            const bool interior = ipx >= 0 && ipy >= 0 && ipx + ext_w < w && ipy + wh < h;
             int r0[SEGLEN + 1], r1[SEGLEN + 1];
-            load_row_u8<SEGLEN>(imgI, ipitch, w, h, ipx + x0, ipy + r, r0);
-            load_row_u8<SEGLEN>(imgI, ipitch, w, h, ipx + x0, ipy + r + 1, r1);
+            load_row_u8<SEGLEN>(imgI, ipitch, w, h, ipx + x0, ipy + rc, interior, r0);
+            load_row_u8<SEGLEN>(imgI, ipitch, w, h, ipx + x0, ipy + rc + 1, interior, r1);
             int gx0r[SEGLEN + 1], gy0r[SEGLEN + 1], gx1r[SEGLEN + 1], gy1r[SEGLEN + 1];
-            load_row_grad<SEGLEN>(grdI, gpitch, w, h, ipx + x0, ipy + r, gx0r, gy0r);
-            load_row_grad<SEGLEN>(grdI, gpitch, w, h, ipx + x0, ipy + r + 1, gx1r, gy1r);
+            load_row_grad<SEGLEN>(grdI, gpitch, w, h, ipx + x0, ipy + rc, interior, gx0r, gy0r);
+            load_row_grad<SEGLEN>(grdI, gpitch, w, h, ipx + x0, ipy + rc + 1, interior, gx1r, gy1r);
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int k = 0; k < SEGLEN; k++) {
@@ -191,81 +285,88 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 Iw[k] = iv; Gx[k] = ix; Gy[k] = iy;
                 a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
             }
-            // normal matrix
-            const float FLT_SCALE = 1.f / (1 << 20);
-            const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
-            const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
-            const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
-            float D = A11 * A22 - A12 * A12;
-            const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
-            if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = minEig;
-            if ((double)minEig < a.min_eig || D < 1.1920928955078125e-07f) {
-                if (level == 0) st = 0;
-                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
-                continue;
-            }
-            D = 1.f / D;
+            A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
+            A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
+            A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+        }
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
+        if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = minEig;
+        if ((double)minEig < a.min_eig || D < 1.1920928955078125e-07f) {
+            if (level == 0) st = 0;
+            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+            continue;
+        }
+        D = 1.f / D;
 
-            // ---- Newton iterations on the target image ----
-            const uint8_t* imgJ = level_img(a.A, img_J, level);
-            nx -= half_x; ny -= half_y;
-            float pdx = 0.f, pdy = 0.f;
-            n_iter = 0;
-            for (int j = 0; j < a.max_iter; j++) {
-                const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-                if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
-                    if (level == 0) st = 0;
-                    break;
-                }
-                n_iter = j + 1;
-                const BilinW jw = bilin_weights(nx - inx, ny - iny);
-                int j0[SEGLEN + 1], j1[SEGLEN + 1];
-                load_row_u8<SEGLEN>(imgJ, ipitch, w, h, inx + x0, iny + r, j0);
-                load_row_u8<SEGLEN>(imgJ, ipitch, w, h, inx + x0, iny + r + 1, j1);
-                int b1 = 0, b2 = 0;
+        // ---- Newton iterations on the target image, fed from LDS ----
+        const uint8_t* imgJ = level_img(a.A, img_J, level);
+        nx -= half_x; ny -= half_y;
+        float pdx = 0.f, pdy = 0.f;
+        n_iter = 0;
+        JRegion R;
+        R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
+        for (int j = 0; j < a.max_iter; j++) {
+            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
+            if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            n_iter = j + 1;
+            if (!region_holds(R, inx, iny, ext_w, wh)) R = stage_region(jlds, imgJ, ipitch, w, h, inx, iny, ext_w, wh, lane);
+            const BilinW jw = bilin_weights(nx - inx, ny - iny);
+            const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
+            uint32_t p0[SEGLEN], p1[SEGLEN];
+            const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
+            read_row_pairs<SEGLEN>(jlds, row, boff, p0);
+            read_row_pairs<SEGLEN>(jlds, row + 1, boff, p1);
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int k = 0; k < SEGLEN; k++) {
+                const int diff = (dot2_acc(p1[k], wbot, dot2_acc(p0[k], wtop, 256)) >> 9) - Iw[k];
+                b1 += diff * Gx[k];
+                b2 += diff * Gy[k];
+            }
+            const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
+            const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            nx += dx; ny += dy;
+            outx = nx + half_x; outy = ny + half_y;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+
+        // ---- residual at the final position (level 0 only) ----
+        if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
+            const float qx = outx - half_x, qy = outy - half_y;
+            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
+            if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
+                st = 0;
+            } else {
+                if (!region_holds(R, iqx, iqy, ext_w, wh)) R = stage_region(jlds, imgJ, ipitch, w, h, iqx, iqy, ext_w, wh, lane);
+                const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
+                const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
+                uint32_t p0[SEGLEN], p1[SEGLEN];
+                const int boff = iqx - R.rx0 + x0, row = iqy - R.ry0 + rc;
+                read_row_pairs<SEGLEN>(jlds, row, boff, p0);
+                read_row_pairs<SEGLEN>(jlds, row + 1, boff, p1);
+                int e = 0;
 #pragma unroll
                 for (int k = 0; k < SEGLEN; k++) {
-                    const int diff = descale(j0[k] * jw.w00 + j0[k + 1] * jw.w01 + j1[k] * jw.w10 + j1[k + 1] * jw.w11, 9) - Iw[k];
-                    b1 += diff * Gx[k];
-                    b2 += diff * Gy[k];
+                    const int diff = (dot2_acc(p1[k], wbot, dot2_acc(p0[k], wtop, 256)) >> 9) - Iw[k];
+                    if (row_ok && (x0 + k < ww)) e += abs(diff);
                 }
-                const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
-                const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
-                const float dx = (A12 * fb2 - A22 * fb1) * D;
-                const float dy = (A12 * fb1 - A11 * fb2) * D;
-                nx += dx; ny += dy;
-                outx = nx + half_x; outy = ny + half_y;
-                if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
-                if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
-                    outx -= dx * 0.5f; outy -= dy * 0.5f;
-                    break;
-                }
-                pdx = dx; pdy = dy;
-            }
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
-
-            // ---- residual at the final position (level 0 only) ----
-            if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
-                const float qx = outx - half_x, qy = outy - half_y;
-                const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
-                if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
-                    st = 0;
-                } else {
-                    const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
-                    int j0[SEGLEN + 1], j1[SEGLEN + 1];
-                    load_row_u8<SEGLEN>(imgJ, ipitch, w, h, iqx + x0, iqy + r, j0);
-                    load_row_u8<SEGLEN>(imgJ, ipitch, w, h, iqx + x0, iqy + r + 1, j1);
-                    int e = 0;
-#pragma unroll
-                    for (int k = 0; k < SEGLEN; k++) {
-                        const int diff = descale(j0[k] * qw.w00 + j0[k + 1] * qw.w01 + j1[k] * qw.w10 + j1[k + 1] * qw.w11, 9) - Iw[k];
-                        if (row_ok && (x0 + k < ww)) e += abs(diff);
-                    }
-                    const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
-                    errv = errsum * 1.f / (float)(32 * ww * wh);
-                }
+                const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
+                errv = errsum * 1.f / (float)(32 * ww * wh);
             }
         }
+        __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
     }
 
     if (lane == 0) {

@@ -128,4 +128,25 @@ __global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, int 
     }
 }
 
+// ---- batched frame ingest: n device-resident frames -> level 0 of their slots, one launch ----
+constexpr int FRAME_PTRS = 128;
+struct FramePtrs {
+    const uint8_t* p[FRAME_PTRS];
+};
+struct __attribute__((packed)) U4Unaligned { uint32_t a, b, c, d; };
+
+__global__ void __launch_bounds__(256) ingest_kernel(ArenaDesc A, ImgList L, FramePtrs F, int first, int w, int h, uint64_t sstride) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* __restrict__ src = F.p[blockIdx.z] + (uint64_t)y * sstride + x;
+    uint8_t* __restrict__ dst = level_img_w(A, L.idx[first + blockIdx.z], 0) + (size_t)y * A.lv[0].img_pitch + x;
+    if (x + 16 <= w) {
+        const U4Unaligned v = *reinterpret_cast<const U4Unaligned*>(src);   // source rows may have any alignment
+        *reinterpret_cast<uint4*>(dst) = make_uint4(v.a, v.b, v.c, v.d);
+    } else {
+        for (int k = 0; x + k < w; k++) dst[k] = src[k];
+    }
+}
+
 }  // namespace ftd

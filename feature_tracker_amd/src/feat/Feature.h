@@ -21,6 +21,19 @@ public:
     std::array<double, 3> p_FinA{{0, 0, 0}};
     std::array<double, 3> p_FinG{{0, 0, 0}};
 
+    // append one observation; the three per-camera vectors of the camera used last are remembered, so a track that
+    // stays in one camera costs three push_backs and no hash lookups (map nodes never move)
+    void append(size_t cam_id, float u, float v, float u_n, float v_n, double timestamp) {
+        if (!hot_ts || hot_cam != cam_id) {
+            hot_cam = cam_id;
+            hot_uv = &uvs[cam_id]; hot_uvn = &uvs_norm[cam_id]; hot_ts = &timestamps[cam_id];
+            if (hot_ts->capacity() < 16) { hot_uv->reserve(16); hot_uvn->reserve(16); hot_ts->reserve(16); }
+        }
+        hot_uv->push_back({{u, v}});
+        hot_uvn->push_back({{u_n, v_n}});
+        hot_ts->push_back(timestamp);
+    }
+
     // keep only measurements taken at one of valid_times (src/feat/Feature.cpp:29-58)
     void clean_old_measurements(const std::vector<double>& valid_times) {
         filter([&](double t) { return std::find(valid_times.begin(), valid_times.end(), t) != valid_times.end(); });
@@ -36,6 +49,11 @@ public:
     }
 
 private:
+    size_t hot_cam = 0;
+    std::vector<std::array<float, 2>>* hot_uv = nullptr;
+    std::vector<std::array<float, 2>>* hot_uvn = nullptr;
+    std::vector<double>* hot_ts = nullptr;
+
     template <class Keep>
     void filter(Keep keep) {
         for (auto& kv : timestamps) {

@@ -10,7 +10,8 @@
 
 namespace feature_tracker {
 
-class FeatureDatabase {
+// cache-line aligned: databases of different streams are updated by different host threads
+class alignas(64) FeatureDatabase {
 public:
     FeatureDatabase() = default;
     FeatureDatabase(const FeatureDatabase&) = delete;
@@ -36,9 +37,20 @@ public:
             f = new Feature();
             f->featid = id;
         }
-        f->uvs[cam_id].push_back({{u, v}});
-        f->uvs_norm[cam_id].push_back({{u_n, v_n}});
-        f->timestamps[cam_id].push_back(timestamp);
+        f->append(cam_id, u, v, u_n, v_n, timestamp);
+    }
+
+    // the same for n observations of one frame under a single lock: uvn holds (u, v, u_n, v_n) per observation
+    void update_features(size_t n, const size_t* ids, double timestamp, size_t cam_id, const float* uvn) {
+        std::lock_guard<std::mutex> lck(mtx);
+        for (size_t i = 0; i < n; i++) {
+            Feature*& f = features_idlookup[ids[i]];
+            if (!f) {
+                f = new Feature();
+                f->featid = ids[i];
+            }
+            f->append(cam_id, uvn[4 * i], uvn[4 * i + 1], uvn[4 * i + 2], uvn[4 * i + 3], timestamp);
+        }
     }
 
     // features whose newest measurement in every camera is older than timestamp (FeatureDatabase.h:133-166)

@@ -2,6 +2,7 @@
 // which each library that compiles this file defines: the product library binds the gfx950 device layer.
 #include "ft_tracker.h"
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -72,11 +73,41 @@ struct ftk_tracker {
     std::unique_ptr<TrackKLT> trk;
 };
 
-struct ftk_batch {
+struct ftk_group {
     std::unique_ptr<FrontendBackend> be;
     std::unique_ptr<TrackKLTBatch> batch;
     void* device_ctx = nullptr;
+    int first = 0, n = 0;
+};
+
+struct ftk_batch {
+    std::unique_ptr<WorkerPool> pool;
+    std::vector<ftk_group> groups;
     std::vector<FrameSource> frames;
+    int n_streams = 0;
+
+    ftk_group* group_of(int stream, int* local) {
+        for (auto& g : groups)
+            if (stream >= g.first && stream < g.first + g.n) { *local = stream - g.first; return &g; }
+        return nullptr;
+    }
+    int fill_frames(const void* const* fr, int on_device, int w, int h, size_t stride) {
+        for (int s = 0; s < n_streams; s++) {
+            if (!fr[s]) return FT_E_INVALID;
+            FrameSource& f = frames[s];
+            f = FrameSource();
+            if (on_device) f.dev = fr[s]; else f.host = (const uint8_t*)fr[s];
+            f.cols = w; f.rows = h; f.step = stride;
+        }
+        return FT_OK;
+    }
+    int complete(ftk_group& g, long long& tracked, long long& attempted) {
+        if (!g.batch->in_flight()) return FT_OK;
+        const int rc = g.batch->complete();
+        tracked += (long long)g.batch->tracked_features();
+        attempted += (long long)g.batch->attempted_features();
+        return rc;
+    }
 };
 
 extern "C" {
@@ -162,15 +193,29 @@ int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, dou
     return (int)ts.size();
 }
 
-int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height) {
+int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height,
+                             int n_groups, int host_threads) {
     if (!out || !valid_options(o) || n_streams < 1 || n_streams > FT_MAX_BATCH || max_width < 1 || max_height < 1) return FT_E_INVALID;
     *out = nullptr;
+    if (n_groups <= 0) n_groups = n_streams >= 8 ? 2 : 1;
+    n_groups = std::min(n_groups, n_streams);
+    if (host_threads <= 0) host_threads = TrackKLTBatch::default_host_threads(n_streams);
     try {
         std::unique_ptr<ftk_batch> b(new ftk_batch());
-        b->be.reset(ftk_make_backend(device, limits_for(*o, n_streams, max_width, max_height), &b->device_ctx));
-        if (!b->be) return FT_E_NODEVICE;
-        b->batch.reset(new TrackKLTBatch(b->be.get(), to_options(*o), n_streams));
+        b->n_streams = n_streams;
+        b->pool.reset(new WorkerPool(host_threads - 1));
         b->frames.resize(n_streams);
+        b->groups.resize(n_groups);
+        int first = 0;
+        for (int g = 0; g < n_groups; g++) {
+            ftk_group& G = b->groups[g];
+            G.first = first;
+            G.n = n_streams / n_groups + (g < n_streams % n_groups ? 1 : 0);
+            first += G.n;
+            G.be.reset(ftk_make_backend(device, limits_for(*o, G.n, max_width, max_height), &G.device_ctx));
+            if (!G.be) return FT_E_NODEVICE;
+            G.batch.reset(new TrackKLTBatch(G.be.get(), to_options(*o), G.n, b->pool.get()));
+        }
         *out = b.release();
         return FT_OK;
     } catch (const std::bad_alloc&) {
@@ -180,45 +225,110 @@ int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_st
     }
 }
 
+int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height) {
+    return ftk_batch_create_grouped(out, device, o, n_streams, max_width, max_height, 0, 0);
+}
+
 void ftk_batch_destroy(ftk_batch* b) { delete b; }
 
 int ftk_batch_set_calibration(ftk_batch* b, int stream, const double* calib8, const double* T_cam_imu) {
-    if (!b || stream < 0 || stream >= b->batch->size() || !calib8) return FT_E_INVALID;
+    int local = 0;
+    ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
+    if (!g || !calib8) return FT_E_INVALID;
     std::map<size_t, Calib8> K;
     std::map<size_t, Mat4d> E;
     calib_maps(1, calib8, T_cam_imu, K, E);
-    b->batch->tracker(stream).set_calibration(K, E);
+    g->batch->tracker(local).set_calibration(K, E);
     return FT_OK;
 }
 
 int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double* am3, const double* wm3) {
-    if (!b || stream < 0 || stream >= b->batch->size() || !am3 || !wm3) return FT_E_INVALID;
-    b->batch->tracker(stream).feed_imu(timestamp, Vec3d{{am3[0], am3[1], am3[2]}}, Vec3d{{wm3[0], wm3[1], wm3[2]}});
+    int local = 0;
+    ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
+    if (!g || !am3 || !wm3) return FT_E_INVALID;
+    g->batch->tracker(local).feed_imu(timestamp, Vec3d{{am3[0], am3[1], am3[2]}}, Vec3d{{wm3[0], wm3[1], wm3[2]}});
     return FT_OK;
 }
 
 int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                    size_t stride, long long* tracked, long long* attempted) {
     if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
-    const int S = b->batch->size();
-    for (int s = 0; s < S; s++) {
-        if (!frames[s]) return FT_E_INVALID;
-        FrameSource& f = b->frames[s];
-        f = FrameSource();
-        if (frames_on_device) f.dev = frames[s]; else f.host = (const uint8_t*)frames[s];
-        f.cols = w; f.rows = h; f.step = stride;
+    int rc = b->fill_frames(frames, frames_on_device, w, h, stride);
+    if (rc != FT_OK) return rc;
+    long long tr = 0, at = 0;
+    for (auto& g : b->groups)   // a frame left in flight by the pipelined variant belongs to an earlier call
+        if ((rc = b->complete(g, tr, at)) != FT_OK) return rc;
+    tr = at = 0;
+    for (auto& g : b->groups)
+        if ((rc = g.batch->begin(timestamps + g.first, b->frames.data() + g.first)) != FT_OK) return rc;
+    for (auto& g : b->groups)
+        if ((rc = b->complete(g, tr, at)) != FT_OK) return rc;
+    if (tracked) *tracked = tr;
+    if (attempted) *attempted = at;
+    return FT_OK;
+}
+
+int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
+                             size_t stride, long long* tracked, long long* attempted) {
+    if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
+    int rc = b->fill_frames(frames, frames_on_device, w, h, stride);
+    if (rc != FT_OK) return rc;
+    long long tr = 0, at = 0;
+    const size_t G = b->groups.size();
+    for (size_t g = 0; g < G; g++) {
+        ftk_group& grp = b->groups[g];
+        if ((rc = b->complete(grp, tr, at)) != FT_OK) return rc;      // its previous frame, overlapped with the device work queued so far
+        if ((rc = grp.batch->begin(timestamps + grp.first, b->frames.data() + grp.first)) != FT_OK) return rc;
     }
-    const int rc = b->batch->feed(timestamps, b->frames.data());
-    if (tracked) *tracked = (long long)b->batch->tracked_features();
-    if (attempted) *attempted = (long long)b->batch->attempted_features();
-    return rc;
+    for (size_t g = 0; g + 1 < G; g++)                                 // the last group stays in flight
+        if ((rc = b->complete(b->groups[g], tr, at)) != FT_OK) return rc;
+    if (G == 1 && (rc = b->complete(b->groups[0], tr, at)) != FT_OK) return rc;
+    if (tracked) *tracked = tr;
+    if (attempted) *attempted = at;
+    return FT_OK;
+}
+
+int ftk_batch_flush(ftk_batch* b, long long* tracked, long long* attempted) {
+    if (!b) return FT_E_INVALID;
+    long long tr = 0, at = 0;
+    for (auto& g : b->groups) {
+        const int rc = b->complete(g, tr, at);
+        if (rc != FT_OK) return rc;
+    }
+    if (tracked) *tracked = tr;
+    if (attempted) *attempted = at;
+    return FT_OK;
 }
 
 int ftk_batch_get_points(ftk_batch* b, int stream, float* xy, uint64_t* ids, int cap) {
-    if (!b || stream < 0 || stream >= b->batch->size()) return FT_E_INVALID;
-    return get_points(b->batch->tracker(stream), 0, xy, ids, cap);
+    int local = 0;
+    ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
+    if (!g) return FT_E_INVALID;
+    return get_points(g->batch->tracker(local), 0, xy, ids, cap);
 }
 
-void* ftk_batch_device_ctx(ftk_batch* b) { return b ? b->device_ctx : nullptr; }
+int ftk_batch_stage_times(ftk_batch* b, double* out8, long long* feeds, int reset) {
+    if (!b || !out8) return FT_E_INVALID;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    long long n = 0;
+    for (auto& g : b->groups) {
+        double t[TrackKLTBatch::ST_COUNT];
+        long long f = 0;
+        g.batch->stage_times(t, &f, reset != 0);
+        for (int i = 0; i < 8; i++) out8[i] += t[i];
+        n = std::max(n, f);
+    }
+    if (feeds) *feeds = n;
+    return FT_OK;
+}
+
+int ftk_batch_groups(ftk_batch* b) { return b ? (int)b->groups.size() : FT_E_INVALID; }
+
+void* ftk_batch_group_ctx(ftk_batch* b, int group) {
+    if (!b || group < 0 || group >= (int)b->groups.size()) return nullptr;
+    return b->groups[group].device_ctx;
+}
+
+void* ftk_batch_device_ctx(ftk_batch* b) { return ftk_batch_group_ctx(b, 0); }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ class FrontendBackend {
 public:
     virtual ~FrontendBackend() = default;
     virtual int upload(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) = 0;
-    virtual int set_frame_device(int stream, int slot, const void* dev, int w, int h, size_t stride) = 0;
+    virtual int set_frames_device(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride) = 0;
     virtual int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
                               int with_gradients, int* achieved) = 0;
     virtual int lk_track_async(int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) = 0;

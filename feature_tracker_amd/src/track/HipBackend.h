@@ -20,8 +20,8 @@ public:
     int upload(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) override {
         return ft_upload(ctx_, stream, slot, host, w, h, stride);
     }
-    int set_frame_device(int stream, int slot, const void* dev, int w, int h, size_t stride) override {
-        return ft_set_frame_device(ctx_, stream, slot, dev, w, h, stride);
+    int set_frames_device(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride) override {
+        return ft_set_frames_device(ctx_, n, streams, slots, dev, w, h, stride);
     }
     int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h, int with_gradients,
                       int* achieved) override {

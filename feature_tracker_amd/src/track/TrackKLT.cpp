@@ -60,7 +60,7 @@ bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float
 // monocular path
 // ---------------------------------------------------------------------------------------------------------------
 
-int TrackKLT::mono_begin(double timestamp, const FrameSource& frame, size_t cam_id, MonoPlan& plan) {
+void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, MonoPlan& plan) {
     CamState& cs = cams[cam_id];
     plan = MonoPlan();
     plan.cam = cam_id;
@@ -68,9 +68,7 @@ int TrackKLT::mono_begin(double timestamp, const FrameSource& frame, size_t cam_
     plan.stream = stream0 + (int)cam_id;
     plan.slot_last = cs.slot_last;
     plan.slot_cur = cs.slot_last == 0 ? 1 : 0;
-    plan.cols = frame.cols; plan.rows = frame.rows;
-    if (frame.dev) return be->set_frame_device(plan.stream, plan.slot_cur, frame.dev, frame.cols, frame.rows, frame.step);
-    return be->upload(plan.stream, plan.slot_cur, frame.host, frame.cols, frame.rows, frame.step);
+    plan.cols = cols; plan.rows = rows;
 }
 
 int TrackKLT::mono_features_needed(const MonoPlan& plan) {
@@ -151,11 +149,14 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
             good.push_back(kp);
             good_ids.push_back(ids[i]);
         }
-        if (camera_k.count(plan.cam)) {
-            for (size_t i = 0; i < good.size(); i++) {   // TrackKLT.cpp:187-192
+        if (camera_k.count(plan.cam)) {          // TrackKLT.cpp:187-192, one database lock for the whole frame
+            std::vector<float>& uvn = plan.prev_xy;   // done with the LK inputs: reuse the storage
+            uvn.resize(4 * good.size());
+            for (size_t i = 0; i < good.size(); i++) {
                 const Point2f npt = undistort_point(good[i].pt, plan.cam);
-                database->update_feature(good_ids[i], plan.timestamp, plan.cam, good[i].pt.x, good[i].pt.y, npt.x, npt.y);
+                uvn[4 * i] = good[i].pt.x; uvn[4 * i + 1] = good[i].pt.y; uvn[4 * i + 2] = npt.x; uvn[4 * i + 3] = npt.y;
             }
+            database->update_features(good.size(), good_ids.data(), plan.timestamp, plan.cam, uvn.data());
         }
         pts.swap(good);
         ids.swap(good_ids);
@@ -177,9 +178,8 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
     std::unique_ptr<std::lock_guard<std::mutex>> lck;
     if (cam_id < mtx_feeds.size()) lck.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id]));
     MonoPlan plan;
-    FrameSource fs;
-    fs.host = img.data; fs.cols = img.cols; fs.rows = img.rows; fs.step = img.step;
-    if (mono_begin(timestamp, fs, cam_id, plan) != FT_OK) return;
+    mono_begin(timestamp, img.cols, img.rows, cam_id, plan);
+    if (be->upload(plan.stream, plan.slot_cur, img.data, img.cols, img.rows, img.step) != FT_OK) return;
     const ft_lk_params prm = lk_params();
     if (be->build_pyramid(1, &plan.stream, &plan.slot_cur, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
 

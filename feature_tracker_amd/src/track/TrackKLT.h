@@ -37,7 +37,8 @@ struct Detection {
     const int* cell_counts = nullptr; // NMS survivors per cell before truncation
 };
 
-class TrackKLT : public TrackBase {
+// cache-line aligned: trackers of different streams are driven by different host threads
+class alignas(64) TrackKLT : public TrackBase {
 public:
     // reference constructor (src/track/TrackKLT.h:58-59) plus the backend and the first backend stream this tracker
     // uses: camera cam_id lives in backend stream stream_base + cam_id
@@ -58,7 +59,7 @@ public:
     void feed_monocular(double timestamp, const Image8& img, size_t cam_id);
 
     // ---- staged monocular interface: lets a driver run many independent trackers through shared batched launches ----
-    struct MonoPlan {
+    struct alignas(64) MonoPlan {
         size_t cam = 0;
         double timestamp = 0;
         int stream = 0, slot_cur = 0, slot_last = 0;
@@ -71,8 +72,8 @@ public:
         float H[9];
         bool use_H = false;
     };
-    // 1. choose slots and enqueue the frame copy
-    int mono_begin(double timestamp, const FrameSource& frame, size_t cam_id, MonoPlan& plan);
+    // 1. choose the ring slot the new frame goes to (the caller ingests the frame into (plan.stream, plan.slot_cur))
+    void mono_begin(double timestamp, int cols, int rows, size_t cam_id, MonoPlan& plan);
     // 2a. (non-speculative only) how many features the previous frame lacks; > 1 means it wants a detection on slot_last
     int mono_features_needed(const MonoPlan& plan);
     // 2b. top the previous frame up from `last_det` (may be invalid = nothing to add) and lay out the LK job

@@ -4,18 +4,31 @@
 // no counterpart in the reference, which runs one stereo rig per process with a host thread per camera
 // (src/track/TrackKLT.cpp:51-58, :91-98).
 #pragma once
+#include <chrono>
 #include <memory>
 #include <vector>
 
+#include "../utils/WorkerPool.h"
 #include "TrackKLT.h"
 
 namespace feature_tracker {
 
 class TrackKLTBatch {
 public:
-    TrackKLTBatch(FrontendBackend* backend, const FeatureTrackerOptions& opt, int n_streams) : be(backend), options(opt) {
+    // shared_pool: workers for the per-stream bookkeeping (nullptr = a private pool of at most 8 threads)
+    TrackKLTBatch(FrontendBackend* backend, const FeatureTrackerOptions& opt, int n_streams, WorkerPool* shared_pool = nullptr)
+        : be(backend), options(opt), pool(shared_pool) {
         for (int s = 0; s < n_streams; s++) trackers.emplace_back(new TrackKLT(backend, opt, 0, s));
         plans.resize(n_streams);
+        if (!pool) {
+            own_pool.reset(new WorkerPool(default_host_threads(n_streams) - 1));   // the calling thread works too
+            pool = own_pool.get();
+        }
+    }
+
+    static int default_host_threads(int n_streams) {
+        const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(std::min(hw > 0 ? hw : 1, 8), n_streams / 4));
     }
 
     int size() const { return (int)trackers.size(); }
@@ -23,19 +36,52 @@ public:
 
     // one frame per stream, all of the same size; returns FT_OK or a device error code
     int feed(const double* timestamps, const FrameSource* frames) {
+        const int rc = begin(timestamps, frames);
+        return rc != FT_OK ? rc : complete();
+    }
+    bool in_flight() const { return pending; }
+
+    // first half of feed(): host preparation and every device launch of the frame set; returns without waiting.
+    // A driver that owns several batches on separate device contexts overlaps one batch's device work with another
+    // batch's host bookkeeping by interleaving begin() and complete() calls.
+    int begin(const double* timestamps, const FrameSource* frames) {
         const int S = size();
         if (S == 0) return FT_OK;
+        using clk = std::chrono::steady_clock;
+        auto mark = clk::now();
+        const auto t_begin = mark;
+        auto lap = [&](int stage) {
+            const auto now = clk::now();
+            stage_s[stage] += std::chrono::duration<double>(now - mark).count();
+            mark = now;
+        };
         TrackKLT& t0 = *trackers[0];
         const int gx = t0.grid_cols(), gy = t0.grid_rows(), kmax = t0.per_cell_max();
         const int cells = Grider_FAST::cells_for(frames[0].cols, frames[0].rows, gx, gy);
         streams.resize(S); cur_slots.resize(S);
         int rc;
+        bool all_dev = true;
         for (int s = 0; s < S; s++) {
-            if ((rc = trackers[s]->mono_begin(timestamps[s], frames[s], 0, plans[s])) != FT_OK) return rc;
+            trackers[s]->mono_begin(timestamps[s], frames[s].cols, frames[s].rows, 0, plans[s]);
             streams[s] = plans[s].stream; cur_slots[s] = plans[s].slot_cur;
+            all_dev &= frames[s].dev != nullptr && frames[s].cols == frames[0].cols && frames[s].rows == frames[0].rows && frames[s].step == frames[0].step;
         }
+        if (all_dev) {   // frames already in HBM: one copy launch for the whole batch
+            dev_ptrs.resize(S);
+            for (int s = 0; s < S; s++) dev_ptrs[s] = frames[s].dev;
+            if ((rc = be->set_frames_device(S, streams.data(), cur_slots.data(), dev_ptrs.data(), frames[0].cols, frames[0].rows, frames[0].step)) != FT_OK) return rc;
+        } else {
+            for (int s = 0; s < S; s++) {
+                const FrameSource& f = frames[s];
+                if (f.dev) rc = be->set_frames_device(1, &streams[s], &cur_slots[s], &f.dev, f.cols, f.rows, f.step);
+                else rc = be->upload(streams[s], cur_slots[s], f.host, f.cols, f.rows, f.step);
+                if (rc != FT_OK) return rc;
+            }
+        }
+        lap(ST_INGEST);
         if ((rc = be->build_pyramid(S, streams.data(), cur_slots.data(), t0.max_level(), t0.window(), t0.window(), 1, nullptr)) != FT_OK) return rc;
 
+        lap(ST_PYRAMID);
         // detections of the previous frames: cached (speculative) or computed now for the streams that need them
         std::vector<Detection> last_det(S);
         if (t0.speculative()) {
@@ -69,16 +115,17 @@ public:
             }
         }
 
+        lap(ST_DETECT);
         jobs.clear();
+        all_jobs.resize(S);
+        pool->parallel_for(S, [&](int s) { trackers[s]->mono_prepare(plans[s], last_det[s], all_jobs[s]); });
         bool any_first = false;
         for (int s = 0; s < S; s++) {
-            ft_lk_job j;
-            trackers[s]->mono_prepare(plans[s], last_det[s], j);
-            if (plans[s].run_lk) jobs.push_back(j);
+            if (plans[s].run_lk) jobs.push_back(all_jobs[s]);
             any_first |= plans[s].first;
         }
+        lap(ST_PREPARE);
         // detector on the new frames: always when speculative, otherwise only for streams that start from nothing
-        std::vector<Detection> cur_det(S);
         if (cells > 0 && (t0.speculative() || any_first)) {
             std::vector<int> d_streams, d_slots, who;
             for (int s = 0; s < S; s++)
@@ -91,26 +138,69 @@ public:
         } else {
             det_who.clear();
         }
+        lap(ST_DETECT);
         if (!jobs.empty()) {
             const ft_lk_params prm = t0.lk_params();
             if ((rc = be->lk_track_async((int)jobs.size(), jobs.data(), &prm)) != FT_OK) return rc;
         }
+        lap(ST_LK_ENQUEUE);
+        stage_s[ST_TOTAL] += std::chrono::duration<double>(mark - t_begin).count();
+        pend_cells = cells; pend_kmax = kmax;
+        pending = true;
+        return FT_OK;
+    }
+
+    // second half of feed(): wait for the device, then masks, feature database and state roll of every stream
+    int complete() {
+        if (!pending) return FT_OK;
+        pending = false;
+        const int S = size();
+        using clk = std::chrono::steady_clock;
+        auto mark = clk::now();
+        const auto t_begin = mark;
+        auto lap = [&](int stage) {
+            const auto now = clk::now();
+            stage_s[stage] += std::chrono::duration<double>(now - mark).count();
+            mark = now;
+        };
+        int rc;
+        const int cells = pend_cells, kmax = pend_kmax;
         if ((rc = be->sync()) != FT_OK) return rc;
+        lap(ST_WAIT);
+        std::vector<Detection>& cur_det = cur_det_buf;
+        cur_det.assign(S, Detection());
         const int cap = cells * kmax;
         for (size_t q = 0; q < det_who.size(); q++) {
             Detection& d = cur_det[det_who[q]];
             d.valid = true; d.per_cell = kmax; d.cells = cells;
             d.kps = det_buf.data() + q * cap; d.n = det_n[q]; d.cell_counts = det_cells.data() + q * cells;
         }
+        pool->parallel_for(S, [&](int s) { trackers[s]->mono_finish(plans[s], cur_det[s]); });
         tracked = 0;
         attempted = 0;
         for (int s = 0; s < S; s++) {
-            const bool ran = plans[s].run_lk;
-            if (ran) attempted += plans[s].status.size();
-            trackers[s]->mono_finish(plans[s], cur_det[s]);
-            if (ran) tracked += trackers[s]->tracked_last(0);
+            if (!plans[s].run_lk) continue;
+            attempted += plans[s].status.size();
+            tracked += trackers[s]->tracked_last(0);
         }
+        lap(ST_FINISH);
+        stage_s[ST_TOTAL] += std::chrono::duration<double>(mark - t_begin).count();
+        n_feeds++;
         return FT_OK;
+    }
+
+    // wall-clock seconds per stage accumulated over feeds (the reference's stage timers, src/track/TrackKLT.cpp:212-217,
+    // adapted to an asynchronous device: enqueue cost per stage, then one wait for everything)
+    enum Stage { ST_INGEST = 0, ST_PYRAMID, ST_DETECT, ST_PREPARE, ST_LK_ENQUEUE, ST_WAIT, ST_FINISH, ST_TOTAL, ST_COUNT };
+    static const char* stage_name(int i) {
+        static const char* names[ST_COUNT] = {"frame ingest", "pyramid enqueue", "detection (host + enqueue)", "klt prepare (top-off, job layout)",
+                                              "klt enqueue", "device wait", "masks + feature DB update", "total"};
+        return names[i];
+    }
+    void stage_times(double* out, long long* feeds, bool reset) {
+        for (int i = 0; i < ST_COUNT; i++) out[i] = stage_s[i];
+        if (feeds) *feeds = n_feeds;
+        if (reset) { for (double& v : stage_s) v = 0; n_feeds = 0; }
     }
 
     size_t tracked_features() const { return tracked; }     // features with final status 1 in the last feed
@@ -122,11 +212,19 @@ private:
     std::vector<std::unique_ptr<TrackKLT>> trackers;
     std::vector<TrackKLT::MonoPlan> plans;
     std::vector<int> streams, cur_slots, det_who;
-    std::vector<ft_lk_job> jobs;
+    std::vector<const void*> dev_ptrs;
+    std::vector<ft_lk_job> jobs, all_jobs;
+    WorkerPool* pool;
+    std::unique_ptr<WorkerPool> own_pool;
+    std::vector<Detection> cur_det_buf;
+    bool pending = false;
+    int pend_cells = 0, pend_kmax = 0;
     std::vector<ft_keypoint> det_buf, last_buf;
     std::vector<int> det_n, det_cells, last_n, last_cells;
     std::vector<std::vector<int>> cached_cells;
     size_t tracked = 0, attempted = 0;
+    double stage_s[ST_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long n_feeds = 0;
 };
 
 }  // namespace feature_tracker

@@ -18,9 +18,9 @@ class ftk_options(C.Structure):
 
 SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "ftk_tracker_set_calibration",
            "ftk_tracker_feed_imu", "ftk_tracker_feed_stereo", "ftk_tracker_feed_monocular", "ftk_tracker_get_points",
-           "ftk_tracker_database_size", "ftk_tracker_get_track", "ftk_batch_create", "ftk_batch_destroy",
-           "ftk_batch_set_calibration", "ftk_batch_feed_imu", "ftk_batch_feed", "ftk_batch_get_points",
-           "ftk_batch_device_ctx", "ftk_backend_name"]
+           "ftk_tracker_database_size", "ftk_tracker_get_track", "ftk_batch_create", "ftk_batch_create_grouped", "ftk_batch_destroy",
+           "ftk_batch_set_calibration", "ftk_batch_feed_imu", "ftk_batch_feed", "ftk_batch_feed_pipelined", "ftk_batch_flush", "ftk_batch_get_points", "ftk_batch_groups", "ftk_batch_group_ctx",
+           "ftk_batch_stage_times", "ftk_batch_device_ctx", "ftk_backend_name"]
 
 _libs = {}
 
@@ -49,12 +49,19 @@ def load_library(lib_path=None):
     L.ftk_tracker_database_size.argtypes = [vp]
     L.ftk_tracker_get_track.argtypes = [vp, C.c_uint64, C.c_int, vp, vp, C.c_int]
     L.ftk_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ftk_options), C.c_int, C.c_int, C.c_int]
+    L.ftk_batch_create_grouped.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(ftk_options), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ftk_batch_destroy.argtypes = [vp]
     L.ftk_batch_destroy.restype = None
     L.ftk_batch_set_calibration.argtypes = [vp, C.c_int, dp, dp]
     L.ftk_batch_feed_imu.argtypes = [vp, C.c_int, C.c_double, dp, dp]
     L.ftk_batch_feed.argtypes = [vp, dp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.ftk_batch_feed_pipelined.argtypes = L.ftk_batch_feed.argtypes
+    L.ftk_batch_flush.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.ftk_batch_get_points.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.ftk_batch_groups.argtypes = [vp]
+    L.ftk_batch_group_ctx.argtypes = [vp, C.c_int]
+    L.ftk_batch_group_ctx.restype = vp
+    L.ftk_batch_stage_times.argtypes = [vp, dp, C.POINTER(C.c_longlong), C.c_int]
     L.ftk_batch_device_ctx.argtypes = [vp]
     L.ftk_batch_device_ctx.restype = vp
     L.ftk_backend_name.argtypes = []
@@ -143,12 +150,13 @@ class Tracker(_Base):
 class BatchTracker(_Base):
     """n independent monocular streams through shared batched launches (TrackKLTBatch)."""
 
-    def __init__(self, n_streams, max_width, max_height, device=0, lib_path=None, **options):
+    def __init__(self, n_streams, max_width, max_height, device=0, lib_path=None, n_groups=0, host_threads=0, **options):
         self.lib = load_library(lib_path)
         self.opts = make_options(self.lib, **options)
         self.n = n_streams
         self._h = C.c_void_p()
-        self._check(self.lib.ftk_batch_create(C.byref(self._h), device, C.byref(self.opts), n_streams, max_width, max_height), "ftk_batch_create")
+        self._check(self.lib.ftk_batch_create_grouped(C.byref(self._h), device, C.byref(self.opts), n_streams, max_width, max_height,
+                                                      n_groups, host_threads), "ftk_batch_create")
         self._ptrs = (C.c_void_p * n_streams)()
         self._ts = np.zeros(n_streams, dtype=np.float64)
 
@@ -180,17 +188,30 @@ class BatchTracker(_Base):
             self._ptrs[i] = f.ctypes.data
         return self._feed(timestamps, 0, w, h, keep[0].strides[0])
 
-    def feed_device(self, timestamps, dev_ptrs, w, h, stride):
-        """dev_ptrs: n device addresses of frames resident in HBM."""
+    def feed_device(self, timestamps, dev_ptrs, w, h, stride, pipelined=False):
+        """dev_ptrs: n device addresses of frames resident in HBM.  pipelined=True leaves the last group's frame in
+        flight (finish with flush()); the returned counts are those of the frames completed by the call."""
         for i, p in enumerate(dev_ptrs):
             self._ptrs[i] = int(p)
-        return self._feed(timestamps, 1, w, h, stride)
+        return self._feed(timestamps, 1, w, h, stride, pipelined)
 
-    def _feed(self, timestamps, on_device, w, h, stride):
+    def _feed(self, timestamps, on_device, w, h, stride, pipelined=False):
         self._ts[:] = timestamps
         tracked, attempted = C.c_longlong(), C.c_longlong()
-        self._check(self.lib.ftk_batch_feed(self._h, _dp(self._ts), self._ptrs, on_device, w, h, stride, C.byref(tracked), C.byref(attempted)), "ftk_batch_feed")
+        fn = self.lib.ftk_batch_feed_pipelined if pipelined else self.lib.ftk_batch_feed
+        self._check(fn(self._h, _dp(self._ts), self._ptrs, on_device, w, h, stride, C.byref(tracked), C.byref(attempted)), "ftk_batch_feed")
         return tracked.value, attempted.value
+
+    def flush(self):
+        tracked, attempted = C.c_longlong(), C.c_longlong()
+        self._check(self.lib.ftk_batch_flush(self._h, C.byref(tracked), C.byref(attempted)), "ftk_batch_flush")
+        return tracked.value, attempted.value
+
+    def groups(self):
+        return self.lib.ftk_batch_groups(self._h)
+
+    def group_ctx(self, g):
+        return self.lib.ftk_batch_group_ctx(self._h, g)
 
     def points(self, stream):
         n = self.lib.ftk_batch_get_points(self._h, stream, None, None, 0)
@@ -198,6 +219,16 @@ class BatchTracker(_Base):
         if n:
             self.lib.ftk_batch_get_points(self._h, stream, xy.ctypes.data, ids.ctypes.data, n)
         return xy, ids
+
+    STAGES = ["frame_ingest", "pyramid_enqueue", "detection", "klt_prepare", "klt_enqueue", "device_wait", "db_update", "total"]
+
+    def stage_times(self, reset=True):
+        """Mean milliseconds per feed for every stage since the last reset."""
+        out = np.zeros(8, dtype=np.float64)
+        feeds = C.c_longlong()
+        self._check(self.lib.ftk_batch_stage_times(self._h, _dp(out), C.byref(feeds), int(reset)), "ftk_batch_stage_times")
+        n = max(1, feeds.value)
+        return {k: 1e3 * v / n for k, v in zip(self.STAGES, out)}
 
     def device_ctx(self):
         return self.lib.ftk_batch_device_ctx(self._h)

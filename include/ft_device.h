@@ -97,9 +97,12 @@ void ft_ctx_destroy(ft_ctx* ctx);
 
 /* Frame ingest.  ft_upload copies the host image into pinned staging (so the caller may reuse its buffer at
  * once, as after the clone() at src/track/TrackKLT.cpp:46-47) and enqueues the H2D copy into level 0.
- * ft_set_frame_device enqueues a device-to-device copy from a frame already resident in HBM. */
+ * ft_set_frame_device enqueues a device-to-device copy from a frame already resident in HBM (asynchronous: the
+ * source must stay valid until the next ft_sync). */
 int ft_upload(ft_ctx* ctx, int stream, int slot, const uint8_t* host, int w, int h, size_t stride);
 int ft_set_frame_device(ft_ctx* ctx, int stream, int slot, const void* dev, int w, int h, size_t stride);
+/* n device-resident frames of one size into n slots with a single copy launch */
+int ft_set_frames_device(ft_ctx* ctx, int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride);
 
 /* Levels 1..max_level by pyrDown and, if with_gradients, Scharr (Ix,Iy) of every level, for n images in one
  * launch per level.  achieved[i] (optional) receives the top level index after the early-stop rule of

@@ -53,8 +53,12 @@ int ftk_tracker_database_size(ftk_tracker* t);
 /* observations of one feature in one camera: returns the count; fills up to cap (u,v,u_n,v_n) rows and timestamps */
 int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
 
-/* ---- n independent monocular streams, batched ---- */
+/* ---- n independent monocular streams, batched ----
+ * The streams are split into `n_groups` groups (0 = choose: 2 when there are at least 8 streams, else 1), each with its
+ * own device context and queue, so that one group's device work overlaps another group's host bookkeeping. */
 int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height);
+int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height,
+                             int n_groups, int host_threads);
 void ftk_batch_destroy(ftk_batch* b);
 int ftk_batch_set_calibration(ftk_batch* b, int stream, const double* calib8, const double* T_cam_imu);
 int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double* am3, const double* wm3);
@@ -62,7 +66,20 @@ int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double*
  * tracked/attempted (optional) receive the number of features with final status 1 / handed to LK. */
 int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                    size_t stride, long long* tracked, long long* attempted);
+/* Software-pipelined feed for sustained throughput: like ftk_batch_feed, but the last group's frame is left in
+ * flight and completed by the next call (or by ftk_batch_flush), so the device never waits for host bookkeeping.
+ * tracked/attempted count the frames COMPLETED by this call. Frames must stay valid until they are completed. */
+int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
+                             size_t stride, long long* tracked, long long* attempted);
+int ftk_batch_flush(ftk_batch* b, long long* tracked, long long* attempted);
 int ftk_batch_get_points(ftk_batch* b, int stream, float* xy, uint64_t* ids, int cap);
+int ftk_batch_groups(ftk_batch* b);
+/* the device context (an ft_ctx*) behind group g */
+void* ftk_batch_group_ctx(ftk_batch* b, int group);
+/* wall-clock seconds per stage accumulated over feeds (8 doubles: frame ingest, pyramid enqueue, detection, klt
+ * prepare, klt enqueue, device wait, masks + feature DB update, total), cf. the stage timers at
+ * src/track/TrackKLT.cpp:212-217 */
+int ftk_batch_stage_times(ftk_batch* b, double* out8, long long* feeds, int reset);
 /* the device context behind the batch (an ft_ctx*), for profiling switches and timers */
 void* ftk_batch_device_ctx(ftk_batch* b);
 const char* ftk_backend_name(void);

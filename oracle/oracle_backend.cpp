@@ -50,8 +50,12 @@ public:
         return FT_OK;
     }
     // the checker has no device: a "device" frame is a host pointer here
-    int set_frame_device(int stream, int slot, const void* dev, int w, int h, size_t stride) override {
-        return upload(stream, slot, (const uint8_t*)dev, w, h, stride);
+    int set_frames_device(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride) override {
+        for (int i = 0; i < n; i++) {
+            const int rc = upload(streams[i], slots[i], (const uint8_t*)dev[i], w, h, stride);
+            if (rc != FT_OK) return rc;
+        }
+        return FT_OK;
     }
     int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h, int, int* achieved) override {
         for (int i = 0; i < n; i++) { Slot* S = at(streams[i], slots[i]); if (!S || S->img.empty()) return FT_E_STATE; }

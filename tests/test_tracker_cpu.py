@@ -146,3 +146,32 @@ def test_mono_tracker_class_matches_batch_of_one(seq):
         t.feed_monocular(seq.timestamps[i], seq.frames[i], 0)
         xy, ids = t.points(0)
         assert np.array_equal(ids, hist[i][3]) and np.array_equal(xy, hist[i][2])
+
+
+def test_pipelined_grouped_feed_equals_plain_feed():
+    seqs = [synth.Sequence(376, 240, 8, stream_id=20 + s) for s in range(8)]
+
+    def run(pipelined, n_groups):
+        b = tracker.BatchTracker(8, 376, 240, lib_path=ORC, n_groups=n_groups, win_size=15, num_pts=80)
+        for s, q in enumerate(seqs):
+            b.set_calibration(s, q.calib8, q.T_cam_imu)
+        total = 0
+        for i in range(8):
+            ts, fr = [q.timestamps[i] for q in seqs], [np.ascontiguousarray(q.frames[i]) for q in seqs]
+            if pipelined:
+                keep = [np.ascontiguousarray(f) for f in fr]
+                for k, f in enumerate(keep):
+                    b._ptrs[k] = f.ctypes.data
+                total += b._feed(ts, 0, 376, 240, 376, pipelined=True)[0]
+                b._keepalive = getattr(b, "_keepalive", []) + [keep]
+            else:
+                total += b.feed_host(ts, fr)[0]
+        total += b.flush()[0]
+        return total, [b.points(s) for s in range(8)]
+
+    ref_total, ref_pts = run(False, 1)
+    for pipelined, groups in ((False, 2), (True, 2), (True, 3), (True, 1)):
+        total, pts = run(pipelined, groups)
+        assert total == ref_total
+        for (xy_a, id_a), (xy_b, id_b) in zip(pts, ref_pts):
+            assert np.array_equal(id_a, id_b) and np.array_equal(xy_a, xy_b)
