@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--groups", type=int, default=0, help="stream groups per GPU (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -143,7 +144,7 @@ def main():
     ptrs = [[dev_frames[s][i].data_ptr() for s in range(S)] for i in range(n_frames)]
     stamps = [[q.timestamps[i] for q in seqs] for i in range(n_frames)]
 
-    b = setup_tracker(tracker, wl, seqs, device=local_rank)
+    b = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=args.groups)
     groups = b.groups()
 
     def barrier():

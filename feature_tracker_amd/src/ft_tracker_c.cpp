@@ -3,8 +3,13 @@
 #include "ft_tracker.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <new>
 
 #include "FeatureTrackerOptions.h"
@@ -73,22 +78,94 @@ struct ftk_tracker {
     std::unique_ptr<TrackKLT> trk;
 };
 
+// One stream group = one device context + one TrackKLTBatch + one host driver thread.  Groups share nothing, so
+// their host bookkeeping and their device queues run concurrently; frames are posted to a two-deep mailbox per
+// group so that a group can start on frame k+1 while the caller still collects frame k.
 struct ftk_group {
     std::unique_ptr<FrontendBackend> be;
     std::unique_ptr<TrackKLTBatch> batch;
     void* device_ctx = nullptr;
     int first = 0, n = 0;
+
+    struct Mail {
+        std::vector<double> ts;
+        std::vector<FrameSource> frames;
+        long long tracked = 0, attempted = 0;
+        int rc = FT_OK;
+    };
+    Mail mail[2];
+    std::thread driver;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<long> posted{0}, done{0};
+    std::atomic<int> sleeping{0};
+    bool stop = false;
+
+    void start() { driver = std::thread([this] { run(); }); }
+    void shutdown() {
+        if (!driver.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        driver.join();
+    }
+    void run() {
+        for (;;) {
+            const long next = done.load(std::memory_order_relaxed) + 1;
+            // stay hot between back-to-back frames; sleep when the caller goes quiet
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            while (posted.load(std::memory_order_acquire) < next && std::chrono::steady_clock::now() < spin_until) {}
+            if (posted.load(std::memory_order_acquire) < next) {
+                std::unique_lock<std::mutex> lk(m);
+                sleeping.store(1, std::memory_order_release);
+                cv.wait(lk, [&] { return stop || posted.load(std::memory_order_acquire) >= next; });
+                sleeping.store(0, std::memory_order_release);
+                if (stop) return;
+            }
+            Mail& M = mail[next & 1];
+            M.rc = batch->begin(M.ts.data(), M.frames.data());
+            if (M.rc == FT_OK) M.rc = batch->complete();
+            // with another set already queued, this set's database writes run inside its begin(), behind the device
+            // work it queues; otherwise write them now so that an idle group is always up to date
+            if (posted.load(std::memory_order_acquire) <= next) batch->flush_db();
+            M.tracked = (long long)batch->tracked_features();
+            M.attempted = (long long)batch->attempted_features();
+            done.store(next, std::memory_order_release);
+        }
+    }
+    // hand frame set `seq` (= posted + 1) to the driver; the previous-but-one set must have been collected
+    void post(const double* ts, const FrameSource* fr) {
+        const long seq = posted.load(std::memory_order_relaxed) + 1;
+        Mail& M = mail[seq & 1];
+        M.ts.assign(ts, ts + n);
+        M.frames.assign(fr, fr + n);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            posted.store(seq, std::memory_order_release);
+        }
+        if (sleeping.load(std::memory_order_acquire)) cv.notify_all();
+    }
+    Mail& wait(long seq) {
+        while (done.load(std::memory_order_acquire) < seq) std::this_thread::yield();
+        return mail[seq & 1];
+    }
 };
 
 struct ftk_batch {
-    std::unique_ptr<WorkerPool> pool;
-    std::vector<ftk_group> groups;
+    std::vector<std::unique_ptr<ftk_group>> groups;
     std::vector<FrameSource> frames;
     int n_streams = 0;
+    long seq = 0;          // frame sets posted so far
+    long collected = 0;    // frame sets whose results were handed to the caller
 
+    ~ftk_batch() {
+        for (auto& g : groups) g->shutdown();
+    }
     ftk_group* group_of(int stream, int* local) {
         for (auto& g : groups)
-            if (stream >= g.first && stream < g.first + g.n) { *local = stream - g.first; return &g; }
+            if (stream >= g->first && stream < g->first + g->n) { *local = stream - g->first; return g.get(); }
         return nullptr;
     }
     int fill_frames(const void* const* fr, int on_device, int w, int h, size_t stride) {
@@ -101,12 +178,27 @@ struct ftk_batch {
         }
         return FT_OK;
     }
-    int complete(ftk_group& g, long long& tracked, long long& attempted) {
-        if (!g.batch->in_flight()) return FT_OK;
-        const int rc = g.batch->complete();
-        tracked += (long long)g.batch->tracked_features();
-        attempted += (long long)g.batch->attempted_features();
+    void post_all(const double* timestamps) {
+        seq++;
+        for (auto& g : groups) g->post(timestamps + g->first, frames.data() + g->first);
+    }
+    // wait for every frame set up to `upto` and add up the counts of those not yet handed out
+    int collect(long upto, long long& tracked, long long& attempted) {
+        int rc = FT_OK;
+        for (; collected < upto; collected++) {
+            for (auto& g : groups) {
+                ftk_group::Mail& M = g->wait(collected + 1);
+                tracked += M.tracked;
+                attempted += M.attempted;
+                if (M.rc != FT_OK) rc = M.rc;
+            }
+        }
         return rc;
+    }
+    // trackers may only be touched by the caller while their group is idle
+    void quiesce() {
+        long long a = 0, b = 0;
+        collect(seq, a, b);
     }
 };
 
@@ -178,9 +270,15 @@ int ftk_tracker_get_points(ftk_tracker* t, int cam, float* xy, uint64_t* ids, in
 
 int ftk_tracker_database_size(ftk_tracker* t) { return t ? (int)t->trk->get_feature_database()->size() : FT_E_INVALID; }
 
+static int get_track(TrackKLT& trk, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
+
 int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap) {
     if (!t) return FT_E_INVALID;
-    Feature* f = t->trk->get_feature_database()->get_feature((size_t)id);
+    return get_track(*t->trk, id, cam, uvn4, timestamps, cap);
+}
+
+static int get_track(TrackKLT& trk, uint64_t id, int cam, float* uvn4, double* timestamps, int cap) {
+    Feature* f = trk.get_feature_database()->get_feature((size_t)id);
     if (!f || !f->timestamps.count((size_t)cam)) return 0;
     const auto& ts = f->timestamps.at((size_t)cam);
     for (size_t i = 0; i < ts.size() && (int)i < cap; i++) {
@@ -197,25 +295,25 @@ int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, 
                              int n_groups, int host_threads) {
     if (!out || !valid_options(o) || n_streams < 1 || n_streams > FT_MAX_BATCH || max_width < 1 || max_height < 1) return FT_E_INVALID;
     *out = nullptr;
-    if (n_groups <= 0) n_groups = n_streams >= 8 ? 2 : 1;
+    if (n_groups <= 0) n_groups = n_streams >= 32 ? 4 : (n_streams >= 8 ? 2 : 1);
     n_groups = std::min(n_groups, n_streams);
-    if (host_threads <= 0) host_threads = TrackKLTBatch::default_host_threads(n_streams);
+    (void)host_threads;   // one driver thread per group; kept in the signature for callers that size thread pools
     try {
         std::unique_ptr<ftk_batch> b(new ftk_batch());
         b->n_streams = n_streams;
-        b->pool.reset(new WorkerPool(host_threads - 1));
         b->frames.resize(n_streams);
-        b->groups.resize(n_groups);
         int first = 0;
         for (int g = 0; g < n_groups; g++) {
-            ftk_group& G = b->groups[g];
+            b->groups.emplace_back(new ftk_group());
+            ftk_group& G = *b->groups.back();
             G.first = first;
             G.n = n_streams / n_groups + (g < n_streams % n_groups ? 1 : 0);
             first += G.n;
             G.be.reset(ftk_make_backend(device, limits_for(*o, G.n, max_width, max_height), &G.device_ctx));
             if (!G.be) return FT_E_NODEVICE;
-            G.batch.reset(new TrackKLTBatch(G.be.get(), to_options(*o), G.n, b->pool.get()));
+            G.batch.reset(new TrackKLTBatch(G.be.get(), to_options(*o), G.n, 1));
         }
+        for (auto& g : b->groups) g->start();
         *out = b.release();
         return FT_OK;
     } catch (const std::bad_alloc&) {
@@ -235,6 +333,7 @@ int ftk_batch_set_calibration(ftk_batch* b, int stream, const double* calib8, co
     int local = 0;
     ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
     if (!g || !calib8) return FT_E_INVALID;
+    b->quiesce();
     std::map<size_t, Calib8> K;
     std::map<size_t, Mat4d> E;
     calib_maps(1, calib8, T_cam_imu, K, E);
@@ -246,6 +345,7 @@ int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double*
     int local = 0;
     ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
     if (!g || !am3 || !wm3) return FT_E_INVALID;
+    // the propagator has its own lock (src/propagator/TrackPropagator.h:201): IMU samples may arrive while frames are tracked
     g->batch->tracker(local).feed_imu(timestamp, Vec3d{{am3[0], am3[1], am3[2]}}, Vec3d{{wm3[0], wm3[1], wm3[2]}});
     return FT_OK;
 }
@@ -253,57 +353,46 @@ int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double*
 int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                    size_t stride, long long* tracked, long long* attempted) {
     if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
-    int rc = b->fill_frames(frames, frames_on_device, w, h, stride);
-    if (rc != FT_OK) return rc;
     long long tr = 0, at = 0;
-    for (auto& g : b->groups)   // a frame left in flight by the pipelined variant belongs to an earlier call
-        if ((rc = b->complete(g, tr, at)) != FT_OK) return rc;
+    int rc = b->collect(b->seq, tr, at);       // a frame set left in flight by the pipelined variant belongs to an earlier call
+    if (rc != FT_OK) return rc;
+    if ((rc = b->fill_frames(frames, frames_on_device, w, h, stride)) != FT_OK) return rc;
     tr = at = 0;
-    for (auto& g : b->groups)
-        if ((rc = g.batch->begin(timestamps + g.first, b->frames.data() + g.first)) != FT_OK) return rc;
-    for (auto& g : b->groups)
-        if ((rc = b->complete(g, tr, at)) != FT_OK) return rc;
+    b->post_all(timestamps);
+    rc = b->collect(b->seq, tr, at);
     if (tracked) *tracked = tr;
     if (attempted) *attempted = at;
-    return FT_OK;
+    return rc;
 }
 
 int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                              size_t stride, long long* tracked, long long* attempted) {
     if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
-    int rc = b->fill_frames(frames, frames_on_device, w, h, stride);
-    if (rc != FT_OK) return rc;
     long long tr = 0, at = 0;
-    const size_t G = b->groups.size();
-    for (size_t g = 0; g < G; g++) {
-        ftk_group& grp = b->groups[g];
-        if ((rc = b->complete(grp, tr, at)) != FT_OK) return rc;      // its previous frame, overlapped with the device work queued so far
-        if ((rc = grp.batch->begin(timestamps + grp.first, b->frames.data() + grp.first)) != FT_OK) return rc;
-    }
-    for (size_t g = 0; g + 1 < G; g++)                                 // the last group stays in flight
-        if ((rc = b->complete(b->groups[g], tr, at)) != FT_OK) return rc;
-    if (G == 1 && (rc = b->complete(b->groups[0], tr, at)) != FT_OK) return rc;
+    int rc = b->collect(b->seq - 1, tr, at);   // the mailboxes are two deep: set seq-1 must be out before seq+1 goes in
+    if (rc != FT_OK) return rc;
+    if ((rc = b->fill_frames(frames, frames_on_device, w, h, stride)) != FT_OK) return rc;
+    b->post_all(timestamps);
+    rc = b->collect(b->seq - 1, tr, at);       // the set before this one; the new set keeps the groups busy meanwhile
     if (tracked) *tracked = tr;
     if (attempted) *attempted = at;
-    return FT_OK;
+    return rc;
 }
 
 int ftk_batch_flush(ftk_batch* b, long long* tracked, long long* attempted) {
     if (!b) return FT_E_INVALID;
     long long tr = 0, at = 0;
-    for (auto& g : b->groups) {
-        const int rc = b->complete(g, tr, at);
-        if (rc != FT_OK) return rc;
-    }
+    const int rc = b->collect(b->seq, tr, at);
     if (tracked) *tracked = tr;
     if (attempted) *attempted = at;
-    return FT_OK;
+    return rc;
 }
 
 int ftk_batch_get_points(ftk_batch* b, int stream, float* xy, uint64_t* ids, int cap) {
     int local = 0;
     ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
     if (!g) return FT_E_INVALID;
+    b->quiesce();
     return get_points(g->batch->tracker(local), 0, xy, ids, cap);
 }
 
@@ -311,10 +400,11 @@ int ftk_batch_stage_times(ftk_batch* b, double* out8, long long* feeds, int rese
     if (!b || !out8) return FT_E_INVALID;
     for (int i = 0; i < 8; i++) out8[i] = 0;
     long long n = 0;
+    b->quiesce();
     for (auto& g : b->groups) {
         double t[TrackKLTBatch::ST_COUNT];
         long long f = 0;
-        g.batch->stage_times(t, &f, reset != 0);
+        g->batch->stage_times(t, &f, reset != 0);
         for (int i = 0; i < 8; i++) out8[i] += t[i];
         n = std::max(n, f);
     }
@@ -322,11 +412,27 @@ int ftk_batch_stage_times(ftk_batch* b, double* out8, long long* feeds, int rese
     return FT_OK;
 }
 
+int ftk_batch_database_size(ftk_batch* b, int stream) {
+    int local = 0;
+    ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
+    if (!g) return FT_E_INVALID;
+    b->quiesce();
+    return (int)g->batch->tracker(local).get_feature_database()->size();
+}
+
+int ftk_batch_get_track(ftk_batch* b, int stream, uint64_t id, float* uvn4, double* timestamps, int cap) {
+    int local = 0;
+    ftk_group* g = b ? b->group_of(stream, &local) : nullptr;
+    if (!g) return FT_E_INVALID;
+    b->quiesce();
+    return get_track(g->batch->tracker(local), id, 0, uvn4, timestamps, cap);
+}
+
 int ftk_batch_groups(ftk_batch* b) { return b ? (int)b->groups.size() : FT_E_INVALID; }
 
 void* ftk_batch_group_ctx(ftk_batch* b, int group) {
     if (!b || group < 0 || group >= (int)b->groups.size()) return nullptr;
-    return b->groups[group].device_ctx;
+    return b->groups[group]->device_ctx;
 }
 
 void* ftk_batch_device_ctx(ftk_batch* b) { return ftk_batch_group_ctx(b, 0); }

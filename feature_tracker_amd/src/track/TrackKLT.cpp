@@ -149,14 +149,15 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
             good.push_back(kp);
             good_ids.push_back(ids[i]);
         }
-        if (camera_k.count(plan.cam)) {          // TrackKLT.cpp:187-192, one database lock for the whole frame
-            std::vector<float>& uvn = plan.prev_xy;   // done with the LK inputs: reuse the storage
-            uvn.resize(4 * good.size());
+        if (camera_k.count(plan.cam)) {          // TrackKLT.cpp:187-192: undistort now, write the database in mono_commit
+            plan.db_uvn.resize(4 * good.size());
             for (size_t i = 0; i < good.size(); i++) {
                 const Point2f npt = undistort_point(good[i].pt, plan.cam);
-                uvn[4 * i] = good[i].pt.x; uvn[4 * i + 1] = good[i].pt.y; uvn[4 * i + 2] = npt.x; uvn[4 * i + 3] = npt.y;
+                plan.db_uvn[4 * i] = good[i].pt.x; plan.db_uvn[4 * i + 1] = good[i].pt.y;
+                plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
             }
-            database->update_features(good.size(), good_ids.data(), plan.timestamp, plan.cam, uvn.data());
+            plan.db_ids = good_ids;
+            plan.db_pending = true;
         }
         pts.swap(good);
         ids.swap(good_ids);
@@ -172,6 +173,12 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
     cs.slot_last = plan.slot_cur;
     cs.cols = plan.cols; cs.rows = plan.rows;
     cs.t_last = plan.timestamp;
+}
+
+void TrackKLT::mono_commit(MonoPlan& plan) {
+    if (!plan.db_pending) return;
+    plan.db_pending = false;
+    database->update_features(plan.db_ids.size(), plan.db_ids.data(), plan.timestamp, plan.cam, plan.db_uvn.data());
 }
 
 void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id) {
@@ -222,6 +229,7 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
         cur_det.kps = det_buf.data(); cur_det.n = cur_n; cur_det.cell_counts = det_cells.data();
     }
     mono_finish(plan, cur_det);
+    mono_commit(plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

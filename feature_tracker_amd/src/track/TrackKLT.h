@@ -71,6 +71,10 @@ public:
         std::vector<uint8_t> status;
         float H[9];
         bool use_H = false;
+        // observations of this frame waiting to be written to the feature database (see mono_commit)
+        std::vector<size_t> db_ids;
+        std::vector<float> db_uvn;   // u, v, u_n, v_n per observation
+        bool db_pending = false;
     };
     // 1. choose the ring slot the new frame goes to (the caller ingests the frame into (plan.stream, plan.slot_cur))
     void mono_begin(double timestamp, int cols, int rows, size_t cam_id, MonoPlan& plan);
@@ -78,8 +82,12 @@ public:
     int mono_features_needed(const MonoPlan& plan);
     // 2b. top the previous frame up from `last_det` (may be invalid = nothing to add) and lay out the LK job
     void mono_prepare(MonoPlan& plan, const Detection& last_det, ft_lk_job& job_out);
-    // 3. after the LK results are in: bookkeeping; cur_det = detection of the current frame (first-frame case / cache)
+    // 3. after the LK results are in: masks and state roll; cur_det = detection of the current frame (first-frame case /
+    //    cache).  The frame's observations are left in the plan ...
     void mono_finish(MonoPlan& plan, const Detection& cur_det);
+    // 4. ... and written to the feature database here (src/track/TrackKLT.cpp:187-198).  Nothing in the next frame's
+    //    tracking depends on it, so a driver may run it while the device works on the next frame.
+    void mono_commit(MonoPlan& plan);
 
     ft_lk_params lk_params() const;
     int per_cell_max() const { return num_features / (grid_x * grid_y) + 1; }

@@ -15,15 +15,15 @@ namespace feature_tracker {
 
 class TrackKLTBatch {
 public:
-    // shared_pool: workers for the per-stream bookkeeping (nullptr = a private pool of at most 8 threads)
-    TrackKLTBatch(FrontendBackend* backend, const FeatureTrackerOptions& opt, int n_streams, WorkerPool* shared_pool = nullptr)
-        : be(backend), options(opt), pool(shared_pool) {
+    // host_threads: threads for the per-stream bookkeeping, the calling thread included (0 = choose, at most 8)
+    TrackKLTBatch(FrontendBackend* backend, const FeatureTrackerOptions& opt, int n_streams, int host_threads = 0)
+        : be(backend), options(opt) {
         for (int s = 0; s < n_streams; s++) trackers.emplace_back(new TrackKLT(backend, opt, 0, s));
         plans.resize(n_streams);
-        if (!pool) {
-            own_pool.reset(new WorkerPool(default_host_threads(n_streams) - 1));   // the calling thread works too
-            pool = own_pool.get();
-        }
+        db_plans.resize(n_streams);
+        if (host_threads <= 0) host_threads = default_host_threads(n_streams);
+        own_pool.reset(new WorkerPool(host_threads - 1));
+        pool = own_pool.get();
     }
 
     static int default_host_threads(int n_streams) {
@@ -36,8 +36,17 @@ public:
 
     // one frame per stream, all of the same size; returns FT_OK or a device error code
     int feed(const double* timestamps, const FrameSource* frames) {
-        const int rc = begin(timestamps, frames);
-        return rc != FT_OK ? rc : complete();
+        int rc = begin(timestamps, frames);
+        if (rc == FT_OK) rc = complete();
+        flush_db();
+        return rc;
+    }
+    // write the observations of the last completed frame set to the feature databases (begin() does this for the
+    // previous set after it has queued the device work of the new one)
+    void flush_db() {
+        if (!db_pending) return;
+        db_pending = false;
+        pool->parallel_for(size(), [&](int s) { trackers[s]->mono_commit(db_plans[s]); });
     }
     bool in_flight() const { return pending; }
 
@@ -115,21 +124,18 @@ public:
             }
         }
 
-        lap(ST_DETECT);
-        jobs.clear();
-        all_jobs.resize(S);
-        pool->parallel_for(S, [&](int s) { trackers[s]->mono_prepare(plans[s], last_det[s], all_jobs[s]); });
+        // streams without previous points detect on the new frame and return (src/track/TrackKLT.cpp:63-72)
+        starts_fresh.assign(S, 0);
         bool any_first = false;
         for (int s = 0; s < S; s++) {
-            if (plans[s].run_lk) jobs.push_back(all_jobs[s]);
-            any_first |= plans[s].first;
+            starts_fresh[s] = plans[s].slot_last < 0 || trackers[s]->tracked_last(0) == 0;
+            any_first |= starts_fresh[s] != 0;
         }
-        lap(ST_PREPARE);
         // detector on the new frames: always when speculative, otherwise only for streams that start from nothing
         if (cells > 0 && (t0.speculative() || any_first)) {
             std::vector<int> d_streams, d_slots, who;
             for (int s = 0; s < S; s++)
-                if (t0.speculative() || plans[s].first) { who.push_back(s); d_streams.push_back(plans[s].stream); d_slots.push_back(plans[s].slot_cur); }
+                if (t0.speculative() || starts_fresh[s]) { who.push_back(s); d_streams.push_back(plans[s].stream); d_slots.push_back(plans[s].slot_cur); }
             const int cap = cells * kmax;
             det_buf.resize((size_t)who.size() * cap); det_n.resize(who.size()); det_cells.resize((size_t)who.size() * cells);
             if ((rc = be->fast_grid_async((int)who.size(), d_streams.data(), d_slots.data(), t0.fast_threshold(), gx, gy, kmax,
@@ -139,11 +145,20 @@ public:
             det_who.clear();
         }
         lap(ST_DETECT);
+        jobs.clear();
+        all_jobs.resize(S);
+        pool->parallel_for(S, [&](int s) { trackers[s]->mono_prepare(plans[s], last_det[s], all_jobs[s]); });
+        for (int s = 0; s < S; s++)
+            if (plans[s].run_lk) jobs.push_back(all_jobs[s]);
+        lap(ST_PREPARE);
+        lap(ST_DETECT);
         if (!jobs.empty()) {
             const ft_lk_params prm = t0.lk_params();
             if ((rc = be->lk_track_async((int)jobs.size(), jobs.data(), &prm)) != FT_OK) return rc;
         }
         lap(ST_LK_ENQUEUE);
+        flush_db();   // the previous set's database writes overlap the device work queued above
+        lap(ST_FINISH);
         stage_s[ST_TOTAL] += std::chrono::duration<double>(mark - t_begin).count();
         pend_cells = cells; pend_kmax = kmax;
         pending = true;
@@ -176,6 +191,15 @@ public:
             d.kps = det_buf.data() + q * cap; d.n = det_n[q]; d.cell_counts = det_cells.data() + q * cells;
         }
         pool->parallel_for(S, [&](int s) { trackers[s]->mono_finish(plans[s], cur_det[s]); });
+        for (int s = 0; s < S; s++)
+            if (plans[s].db_pending) { db_pending = true; break; }
+        for (int s = 0; s < S && db_pending; s++) {   // hand the payload to the commit plans right away
+            db_plans[s].db_pending = plans[s].db_pending;
+            if (!plans[s].db_pending) continue;
+            db_plans[s].db_ids.swap(plans[s].db_ids); db_plans[s].db_uvn.swap(plans[s].db_uvn);
+            db_plans[s].timestamp = plans[s].timestamp; db_plans[s].cam = plans[s].cam;
+            plans[s].db_pending = false;
+        }
         tracked = 0;
         attempted = 0;
         for (int s = 0; s < S; s++) {
@@ -210,7 +234,9 @@ private:
     FrontendBackend* be;
     FeatureTrackerOptions options;
     std::vector<std::unique_ptr<TrackKLT>> trackers;
-    std::vector<TrackKLT::MonoPlan> plans;
+    std::vector<TrackKLT::MonoPlan> plans, db_plans;
+    std::vector<char> starts_fresh;
+    bool db_pending = false;
     std::vector<int> streams, cur_slots, det_who;
     std::vector<const void*> dev_ptrs;
     std::vector<ft_lk_job> jobs, all_jobs;

@@ -19,7 +19,7 @@ class ftk_options(C.Structure):
 SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "ftk_tracker_set_calibration",
            "ftk_tracker_feed_imu", "ftk_tracker_feed_stereo", "ftk_tracker_feed_monocular", "ftk_tracker_get_points",
            "ftk_tracker_database_size", "ftk_tracker_get_track", "ftk_batch_create", "ftk_batch_create_grouped", "ftk_batch_destroy",
-           "ftk_batch_set_calibration", "ftk_batch_feed_imu", "ftk_batch_feed", "ftk_batch_feed_pipelined", "ftk_batch_flush", "ftk_batch_get_points", "ftk_batch_groups", "ftk_batch_group_ctx",
+           "ftk_batch_set_calibration", "ftk_batch_feed_imu", "ftk_batch_feed", "ftk_batch_feed_pipelined", "ftk_batch_flush", "ftk_batch_get_points", "ftk_batch_database_size", "ftk_batch_get_track", "ftk_batch_groups", "ftk_batch_group_ctx",
            "ftk_batch_stage_times", "ftk_batch_device_ctx", "ftk_backend_name"]
 
 _libs = {}
@@ -58,6 +58,8 @@ def load_library(lib_path=None):
     L.ftk_batch_feed_pipelined.argtypes = L.ftk_batch_feed.argtypes
     L.ftk_batch_flush.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.ftk_batch_get_points.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.ftk_batch_database_size.argtypes = [vp, C.c_int]
+    L.ftk_batch_get_track.argtypes = [vp, C.c_int, C.c_uint64, vp, vp, C.c_int]
     L.ftk_batch_groups.argtypes = [vp]
     L.ftk_batch_group_ctx.argtypes = [vp, C.c_int]
     L.ftk_batch_group_ctx.restype = vp
@@ -206,6 +208,16 @@ class BatchTracker(_Base):
         tracked, attempted = C.c_longlong(), C.c_longlong()
         self._check(self.lib.ftk_batch_flush(self._h, C.byref(tracked), C.byref(attempted)), "ftk_batch_flush")
         return tracked.value, attempted.value
+
+    def database_size(self, stream):
+        return self.lib.ftk_batch_database_size(self._h, stream)
+
+    def track(self, stream, feat_id):
+        n = self.lib.ftk_batch_get_track(self._h, stream, int(feat_id), None, None, 0)
+        uv, ts = np.zeros((max(n, 0), 4), dtype=np.float32), np.zeros(max(n, 0), dtype=np.float64)
+        if n > 0:
+            self.lib.ftk_batch_get_track(self._h, stream, int(feat_id), uv.ctypes.data, ts.ctypes.data, n)
+        return uv, ts
 
     def groups(self):
         return self.lib.ftk_batch_groups(self._h)

@@ -54,8 +54,9 @@ int ftk_tracker_database_size(ftk_tracker* t);
 int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
 
 /* ---- n independent monocular streams, batched ----
- * The streams are split into `n_groups` groups (0 = choose: 2 when there are at least 8 streams, else 1), each with its
- * own device context and queue, so that one group's device work overlaps another group's host bookkeeping. */
+ * The streams are split into `n_groups` groups (0 = choose: 4 from 32 streams, 2 from 8, else 1).  A group has its own
+ * device context and queue and its own host driver thread, so groups overlap each other's device work and host
+ * bookkeeping.  host_threads is reserved. */
 int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height);
 int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height,
                              int n_groups, int host_threads);
@@ -66,13 +67,16 @@ int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double*
  * tracked/attempted (optional) receive the number of features with final status 1 / handed to LK. */
 int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                    size_t stride, long long* tracked, long long* attempted);
-/* Software-pipelined feed for sustained throughput: like ftk_batch_feed, but the last group's frame is left in
- * flight and completed by the next call (or by ftk_batch_flush), so the device never waits for host bookkeeping.
- * tracked/attempted count the frames COMPLETED by this call. Frames must stay valid until they are completed. */
+/* Pipelined feed for sustained throughput: posts this frame set to the groups and returns once the PREVIOUS set is
+ * complete, so the groups never idle between sets.  tracked/attempted count the set completed by this call;
+ * ftk_batch_flush completes the last one.  Frames must stay valid until their set is complete. */
 int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                              size_t stride, long long* tracked, long long* attempted);
 int ftk_batch_flush(ftk_batch* b, long long* tracked, long long* attempted);
 int ftk_batch_get_points(ftk_batch* b, int stream, float* xy, uint64_t* ids, int cap);
+/* number of features in a stream's database / observations of one feature (as ftk_tracker_get_track) */
+int ftk_batch_database_size(ftk_batch* b, int stream);
+int ftk_batch_get_track(ftk_batch* b, int stream, uint64_t id, float* uvn4, double* timestamps, int cap);
 int ftk_batch_groups(ftk_batch* b);
 /* the device context (an ft_ctx*) behind group g */
 void* ftk_batch_group_ctx(ftk_batch* b, int group);

@@ -167,11 +167,16 @@ def test_pipelined_grouped_feed_equals_plain_feed():
             else:
                 total += b.feed_host(ts, fr)[0]
         total += b.flush()[0]
-        return total, [b.points(s) for s in range(8)]
+        db = [b.database_size(s) for s in range(8)]
+        ids0 = b.points(0)[1]
+        tracks = [b.track(0, int(i))[1].tolist() for i in ids0[:5]]
+        return total, [b.points(s) for s in range(8)], db, tracks
 
-    ref_total, ref_pts = run(False, 1)
+    ref_total, ref_pts, ref_db, ref_tracks = run(False, 1)
+    assert min(ref_db) > 50 and all(len(t) >= 1 for t in ref_tracks)
     for pipelined, groups in ((False, 2), (True, 2), (True, 3), (True, 1)):
-        total, pts = run(pipelined, groups)
+        total, pts, db, tracks = run(pipelined, groups)
         assert total == ref_total
+        assert db == ref_db and tracks == ref_tracks      # deferred database writes all land
         for (xy_a, id_a), (xy_b, id_b) in zip(pts, ref_pts):
             assert np.array_equal(id_a, id_b) and np.array_equal(xy_a, xy_b)
