@@ -39,6 +39,10 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
+# HBM bytes per launch group from rocprofv3 PMC passes (TCC_EA0_RDREQ / WRREQ families, collected in separate runs
+# and corrected for gfx950 as the summaries under profiles/ describe); None where no pass has been made
+MEASURED_TRAFFIC = {}
+
 
 def level_sizes(w, h, max_level):
     out = []
@@ -48,20 +52,33 @@ def level_sizes(w, h, max_level):
     return out
 
 
-def pyramid_kernel_bytes(w, h, max_level):
-    """Algorithmic bytes of the fused pyramid + gradient build of one frame: read every level once, write the
-    gradients (4 B/px) of every level and the next level (1 B/px)."""
+def pyramid_kernel_bytes(w, h, max_level, with_gradients):
+    """Algorithmic bytes of the pyramid build of one frame: read every level that has a successor, write every
+    level above 0; with gradient images additionally read every level and write 4 B/px of (Ix, Iy)."""
     s = [a * b for a, b in level_sizes(w, h, max_level)]
-    return sum(s) + 4 * sum(s) + sum(s[1:])
+    by = sum(s[:-1]) + sum(s[1:])
+    if with_gradients:
+        by += sum(s) + 4 * sum(s)
+    return by
+
+
+def lk_kernel_bytes(win, level_visits, iterations):
+    """Algorithmic bytes of LK: per (feature, level) the template patch of I (1 B/px) and of its gradients (4 B/px),
+    and per Newton iteration one patch of J; patches are (win+1)^2 because of the bilinear footprint."""
+    patch = (win + 1) * (win + 1)
+    return 5 * patch * level_visits + patch * iterations
 
 
 def make_sequences(wl, n_frames, rank, threads):
     from feature_tracker_amd import synth
-    return [synth.Sequence(wl["w"], wl["h"], n_frames, stream_id=rank * 1000 + s, threads=threads) for s in range(wl["streams"])]
+    from feature_tracker_amd.sharding import weak_scaling_stream_ids
+    return [synth.Sequence(wl["w"], wl["h"], n_frames, stream_id=sid, threads=threads)
+            for sid in weak_scaling_stream_ids(wl["streams"], rank)]
 
 
-def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0, n_groups=0):
-    b = tracker_mod.BatchTracker(wl["streams"], wl["w"], wl["h"], device=device, lib_path=lib_path, n_groups=n_groups, **wl["opts"])
+def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0, n_groups=0, host_threads=0):
+    b = tracker_mod.BatchTracker(wl["streams"], wl["w"], wl["h"], device=device, lib_path=lib_path, n_groups=n_groups,
+                                 host_threads=host_threads, **wl["opts"])
     for s, q in enumerate(seqs):
         b.set_calibration(s, q.calib8, q.T_cam_imu)
         for t, g, a in zip(q.imu_t, q.gyro, q.accel):
@@ -81,7 +98,8 @@ def cpu_baseline(wl, seqs, threads, budget_s=20.0):
     lib.fto_set_threads(threads)
     n_streams = min(wl["streams"], max(1, threads))        # sample: as many streams as threads (one each), same shapes
     sub = dict(wl, streams=n_streams)
-    b = setup_tracker(tracker, sub, seqs[:n_streams], lib_path=path)
+    # one stream group driven by the calling thread: the oracle's own worker threads are the only parallelism
+    b = setup_tracker(tracker, sub, seqs[:n_streams], lib_path=path, n_groups=1, host_threads=1)
     n_frames = seqs[0].n_frames
     ts = lambda i: [q.timestamps[i] for q in seqs[:n_streams]]
     fr = lambda i: [q.frames[i] for q in seqs[:n_streams]]
@@ -107,6 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--groups", type=int, default=0, help="stream groups per GPU (0 = library default)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads per GPU (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -144,7 +163,7 @@ def main():
     ptrs = [[dev_frames[s][i].data_ptr() for s in range(S)] for i in range(n_frames)]
     stamps = [[q.timestamps[i] for q in seqs] for i in range(n_frames)]
 
-    b = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=args.groups)
+    b = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=args.groups, host_threads=args.host_threads)
     groups = b.groups()
 
     def barrier():
@@ -187,23 +206,21 @@ def main():
     lib.ft_kernel_times(ctx2, C.byref(kt), 1)
     lib.ft_profile(ctx2, 0)
 
-    if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        c = torch.tensor([tracked, attempted], device=dev, dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tracked_all, attempted_all = float(c[0].item()), float(c[1].item())
-    else:
-        dt_max, tracked_all, attempted_all = dt, float(tracked), float(attempted)
+    from feature_tracker_amd.sharding import reduce_run_totals
+    dt_max, (tracked_all, attempted_all) = reduce_run_totals(dt, [tracked, attempted], device=dev)
 
     if rank == 0:
-        pyr_bytes = pyramid_kernel_bytes(w, h, wl["opts"]["pyr_levels"]) * S     # per launch group (one step)
+        # algorithmic bytes per launch group (= one step of all streams of this GPU)
+        pyr_bytes = pyramid_kernel_bytes(w, h, wl["opts"]["pyr_levels"], with_gradients=False) * S
+        lk_bytes = lk_kernel_bytes(wl["opts"]["win_size"], kt.lk_level_visits, kt.lk_iterations) / max(1, kt.lk_launches)
         kinds = {
-            "pyramid_gradient": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
-            "lk_track": (kt.lk_ms, kt.lk_launches, None),
+            "pyramid": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
+            "lk_track": (kt.lk_ms, kt.lk_launches, lk_bytes),
             "fast_grid": (kt.fast_ms, kt.fast_launches, w * h * S),
         }
+        kernel_names = {"pyramid": "level_kernel (pyrDown, one launch per level, all streams of one step)",
+                        "lk_track": "lk_kernel (template + Newton iterations, all levels, all features of one step)",
+                        "fast_grid": "fast_detect_kernel + fast_topk_kernel (all streams of one step)"}
         per_kernel = {}
         for name, (ms, n, by) in kinds.items():
             if n:
@@ -212,10 +229,16 @@ def main():
                 if by:
                     e.update(algorithmic_bytes=by, achieved_gbs=by / (avg * 1e-3) / 1e9, frac_hbm_peak=by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
                 per_kernel[name] = e
-        pk = per_kernel.get("pyramid_gradient", {})
-        roofline = dict(kernel="level_kernel (fused pyrDown + Scharr, all levels of all streams of one step)", bound="hbm",
-                        achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=pk.get("frac_hbm_peak"), traffic=None)
+        if kt.lk_launches:
+            per_kernel["lk_track"].update(points_per_launch=kt.lk_points / kt.lk_launches,
+                                          level_visits_per_point=kt.lk_level_visits / max(1, kt.lk_points),
+                                          iterations_per_level_visit=kt.lk_iterations / max(1, kt.lk_level_visits))
+        # the roofline entry describes the kernel group that takes the most device time per step
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
+        pk = per_kernel.get(dom, {})
+        roofline = dict(kernel=kernel_names.get(dom), bound="hbm", achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=pk.get("frac_hbm_peak"), traffic=MEASURED_TRAFFIC.get((args.workload, dom)),
+                        avg_launch_ms=pk.get("avg_ms"), algorithmic_bytes_per_launch=pk.get("algorithmic_bytes"))
         out = {
             "metric": "tracked_features_per_sec", "value": tracked_all / dt_max, "unit": "features/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "weak",

@@ -42,6 +42,7 @@ struct PendingLK {
     int total = 0;
     int nlev = 0;
     bool want_iters = false;
+    bool count_work = false;   // profiling: fold the iteration counters into the context's totals
 };
 
 struct PendingFast {
@@ -165,6 +166,11 @@ int deliver_pending(ft_ctx* c) {
             }
             off += n;
         }
+        if (P.count_work) {
+            c->times.lk_points += (long long)N;
+            for (size_t i = 0; i < N * (size_t)P.nlev; i++)
+                if (it[i] >= 0) { c->times.lk_level_visits++; c->times.lk_iterations += it[i]; }
+        }
         P.active = false;
     }
     if (c->fast_pending.active) {
@@ -239,7 +245,8 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
 
 template <int SEGLEN>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
-    hipLaunchKernelGGL((lk_kernel<SEGLEN>), dim3(total), dim3(64), 0, c->q, a);
+    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(total), dim3(64), 0, c->q, a);
+    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(total), dim3(64), 0, c->q, a);
 }
 
 }  // namespace
@@ -479,6 +486,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         total += (size_t)J.n;
         if (J.iters) want_iters = true;
     }
+    if (c->profile) want_iters = true;
     if (total > (size_t)c->lim.max_points) return FT_E_LIMIT;
     const int nlev = prm->max_level + 1;
 
@@ -503,8 +511,6 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         if (P.levels < 1 || Q.levels < 1) return FT_E_STATE;
         if (P.w != Q.w || P.h != Q.h) return FT_E_INVALID;
         const int ml = std::min(prm->max_level, std::min(P.levels, Q.levels) - 1);
-        if (P.grad_levels < ml + 1) return FT_E_STATE;
-        if (fb && Q.grad_levels < ml + 1) return FT_E_STATE;
         if (max_level_all < 0) max_level_all = ml;
         else if (ml != max_level_all) return FT_E_INVALID;   // one batch, one pyramid depth
         dj[j].img_prev = sp; dj[j].img_next = sn; dj[j].w0 = P.w; dj[j].h0 = P.h;
@@ -566,7 +572,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     PendingLK& P = c->lk_pending;
     P.jobs.assign(jobs, jobs + n_jobs);
-    P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.active = true;
+    P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.count_work = c->profile; P.active = true;
     return FT_OK;
 }
 

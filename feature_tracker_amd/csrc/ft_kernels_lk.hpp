@@ -3,12 +3,15 @@
 // Replaces cv::calcOpticalFlowPyrLK / LKTrackerInvoker as called at src/track/TrackKLT.cpp:306 and :402.
 //
 // Lane layout: the win_w x win_h window is cut into row segments of SEGLEN pixels; lane = row * SEGS + segment.
-//  * Template: each lane samples its SEGLEN pixels of I (x32) and of the Scharr gradients once per level and keeps
-//    them in registers.
-//  * Target: the part of J the window can reach (window + a margin of LK_MARGIN pixels on every side) is staged in
-//    LDS once per level with aligned dword loads (REFLECT_101 applied while staging); every Newton iteration then
-//    reads two LDS rows per lane, so the dependent chain position -> pixels -> (b1,b2) -> position never waits on
-//    HBM.  A window that walks out of the staged region re-stages it around the current position.
+//  * Both image regions a level needs are staged in LDS with aligned dword loads issued together at the start of
+//    the level (REFLECT_101 applied while staging): the template region of I (window + 1 pixel of Scharr apron) and
+//    the part of J the window can reach (window + a margin of LK_MARGIN pixels on every side).
+//  * Template: each lane samples its SEGLEN pixels of I (x32) and evaluates the Scharr gradients of its samples from
+//    the staged I region (same arithmetic as the gradient image kernel, so no gradient image has to be read: a
+//    window touches a few bytes of every 128-byte line it crosses, and the 4-byte-per-pixel gradient lines were the
+//    largest part of this kernel's memory traffic).  Samples stay in registers for the whole level.
+//  * Target: every Newton iteration reads two LDS rows per lane, so the dependent chain position -> pixels ->
+//    (b1,b2) -> position never waits on memory.  A window that walks out of the staged region re-stages it.
 //  * Sums are exact integers: lanes accumulate in int32, the wave reduction runs on 16-bit halves with DPP adds
 //    (no LDS traffic), and the total is rounded to float once, so results do not depend on the reduction order.
 #pragma once
@@ -83,89 +86,90 @@ __device__ inline int dot2_acc(uint32_t pair, uint32_t wpair, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, pair), __builtin_bit_cast(lk_v2s, wpair), acc, false);
 }
 
-struct __attribute__((packed)) U32Unaligned { uint32_t v; };
-
-// ---- template loads: SEGLEN+1 pixels of row y from column x ----
-template <int SEGLEN>
-__device__ inline void load_row_u8(const uint8_t* __restrict__ img, uint32_t pitch, int w, int h, int x, int y, bool interior, int (&out)[SEGLEN + 1]) {
-    if (interior) {   // wave-uniform: the whole window lies inside the image
-        const uint8_t* p = img + (size_t)y * pitch + x;
-#pragma unroll
-        for (int q = 0; q < SEGLEN / 4; q++) {
-            const uint32_t v = reinterpret_cast<const U32Unaligned*>(p + 4 * q)->v;
-            out[4 * q] = v & 0xff; out[4 * q + 1] = (v >> 8) & 0xff; out[4 * q + 2] = (v >> 16) & 0xff; out[4 * q + 3] = v >> 24;
-        }
-        out[SEGLEN] = p[SEGLEN];
-    } else {
-        const uint8_t* row = img + (size_t)reflect101(y, h) * pitch;
-#pragma unroll
-        for (int k = 0; k <= SEGLEN; k++) out[k] = row[reflect101(x + k, w)];
-    }
-}
-
-// SEGLEN+1 gradient samples of row y from column x; zero outside the image
-template <int SEGLEN>
-__device__ inline void load_row_grad(const uint8_t* __restrict__ grad, uint32_t pitch, int w, int h, int x, int y, bool interior, int (&gx)[SEGLEN + 1], int (&gy)[SEGLEN + 1]) {
-    if (interior) {
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(grad + (size_t)y * pitch) + x;
-#pragma unroll
-        for (int k = 0; k <= SEGLEN; k++) {
-            const uint32_t v = row[k];
-            gx[k] = (int)(int16_t)(v & 0xffff);
-            gy[k] = (int)v >> 16;
-        }
-    } else {
-        const bool row_in = (y >= 0 && y < h);
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(grad + (size_t)(row_in ? y : 0) * pitch);
-#pragma unroll
-        for (int k = 0; k <= SEGLEN; k++) {
-            const int xx = x + k;
-            uint32_t v = 0;
-            if (row_in && xx >= 0 && xx < w) v = row[xx];
-            gx[k] = (int)(int16_t)(v & 0xffff);
-            gy[k] = (int)v >> 16;
-        }
-    }
-}
-
-// ---- target region in LDS ----
-struct JRegion {
+// ---- image regions in LDS ----
+struct Region {
     int rx0, ry0;     // image coordinates of the region origin (rx0 is a multiple of 4)
     int rwd, rh;      // size in dwords x rows
 };
 
-// stage the region that a window at integer origin (inx, iny) can reach within LK_MARGIN pixels
-__device__ inline JRegion stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
-                                       int inx, int iny, int ext_w, int win_h, int lane) {
-    JRegion R;
-    R.rx0 = ((inx - LK_MARGIN) >> 2) << 2;
-    R.ry0 = iny - LK_MARGIN;
-    R.rwd = (inx + ext_w + 1 + LK_MARGIN - R.rx0 + 3) >> 2;    // <= LK_RW_DWORDS
-    R.rh = win_h + 1 + 2 * LK_MARGIN;                          // <= LK_RH_MAX
+// single-reflection REFLECT_101: exact for -len < p < 2*len - 1
+__device__ inline int reflect101_once(int p, int len) {
+    p = p < 0 ? -p : p;
+    return p >= len ? 2 * len - 2 - p : p;
+}
+
+constexpr int LK_REACH = FT_MAX_WIN + 1 + LK_MARGIN + 4;   // farthest a staged region extends beyond a window origin
+
+// load image columns [x_first, x_last] x rows [y_first, y_first + n_rows) into LDS (REFLECT_101 outside the image).
+// Lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...  On levels larger than the reach
+// of a region (all but degenerate ones) a lane issues all its loads before the first one is consumed, so a region
+// costs one memory round trip.  The caller orders the LDS writes before its reads with lds_fence().
+template <int MAXR>
+__device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
+                                               int x_first, int x_last, int y_first, int n_rows, int lane) {
+    Region R;
+    R.rx0 = (x_first >> 2) << 2;
+    R.ry0 = y_first;
+    R.rwd = (x_last - R.rx0 + 4) >> 2;     // <= LK_RW_DWORDS
+    R.rh = n_rows;                         // <= 4 * MAXR
     const int c = lane & 15, rr = lane >> 4;
-    if (c < R.rwd) {
-        const int gx = R.rx0 + 4 * c;
-        const bool col_in = gx >= 0 && gx + 3 < w;
+    const int gx = R.rx0 + 4 * c;
+    const bool col_used = c < R.rwd;
+    const bool col_in = gx >= 0 && gx + 3 < w;
+    const bool roomy = w > 2 * LK_REACH && h > 2 * LK_REACH;   // wave-uniform
+    if (roomy && (col_in || !col_used)) {
+        const uint32_t xoff = col_used ? (uint32_t)gx : 0u;     // unused lanes load something harmless
+        uint32_t v[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; k++) {
+            const int sy = reflect101_once(R.ry0 + min(rr + 4 * k, R.rh - 1), h);
+            v[k] = *reinterpret_cast<const uint32_t*>(img + ((uint32_t)sy * pitch + xoff));   // uniform base + 32-bit offset
+        }
+        if (col_used) {
+#pragma unroll
+            for (int k = 0; k < MAXR; k++)
+                if (rr + 4 * k < R.rh) lds[(rr + 4 * k) * LK_RW_DWORDS + c] = v[k];
+        }
+    } else if (col_used) {   // dword straddles the image border, or a degenerate level: byte by byte, general reflection
+#pragma unroll 1
         for (int row = rr; row < R.rh; row += 4) {
             const uint8_t* src = img + (size_t)reflect101(R.ry0 + row, h) * pitch;
-            uint32_t v;
-            if (col_in) {
-                v = *reinterpret_cast<const uint32_t*>(src + gx);
-            } else {
-                v = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect101(gx + k, w)] << (8 * k);
-            }
-            lds[row * LK_RW_DWORDS + c] = v;
+            uint32_t t = 0;
+#pragma unroll 1
+            for (int b = 0; b < 4; b++) t |= (uint32_t)src[reflect101(gx + b, w)] << (8 * b);
+            lds[row * LK_RW_DWORDS + c] = t;
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes are done (one wave per workgroup)
-    __builtin_amdgcn_wave_barrier();
     return R;
 }
 
-__device__ inline bool region_holds(const JRegion& R, int inx, int iny, int ext_w, int win_h) {
+// one wave per workgroup: LDS operations of a wave complete in order, this only pins the compiler's ordering
+__device__ inline void lds_fence() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline bool region_holds(const Region& R, int inx, int iny, int ext_w, int win_h) {
     return inx >= R.rx0 && inx + ext_w + 1 <= R.rx0 + 4 * R.rwd && iny >= R.ry0 && iny + win_h + 1 <= R.ry0 + R.rh;
+}
+
+// N consecutive bytes of one staged row starting at byte offset byte_off, as ints
+template <int N>
+__device__ inline void read_row_bytes(const uint32_t* __restrict__ lds, int row, int byte_off, int (&out)[N]) {
+    constexpr int NDW = (N + 3 + 3) / 4;
+    const uint32_t* p = lds + row * LK_RW_DWORDS + (byte_off >> 2);
+    const uint32_t sh = byte_off & 3;
+    uint32_t d[NDW + 1];
+#pragma unroll
+    for (int q = 0; q < NDW; q++) d[q] = p[q];
+    d[NDW] = 0;
+#pragma unroll
+    for (int q = 0; q < (N + 3) / 4; q++) {
+        const uint32_t e = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (4 * q + b < N) out[4 * q + b] = (e >> (8 * b)) & 0xff;
+    }
 }
 
 // (J[k], J[k+1]) pairs, k = 0..SEGLEN-1, of one staged row as packed 16-bit pairs for v_dot2
@@ -190,9 +194,14 @@ __device__ inline void read_row_pairs(const uint32_t* __restrict__ lds, int row,
     }
 }
 
-template <int SEGLEN>
+// SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more staged rows per lane)
+template <int SEGLEN, bool TALL>
 __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
-    __shared__ uint32_t jlds[LK_RH_MAX * LK_RW_DWORDS + 4];   // + slack: row reads are dword-granular
+    constexpr int WH_MAX = TALL ? 32 : 21;
+    constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
+    constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
+    __shared__ uint32_t jlds[LK_RH_MAX * LK_RW_DWORDS + 4];         // target region (+ slack: row reads are dword-granular)
+    __shared__ uint32_t ilds[(32 + 3) * LK_RW_DWORDS + 4];          // template region: window + Scharr apron
     const int pt = blockIdx.x;
     const int lane = threadIdx.x;
     const LKJobDev* job = a.jobs + a.pt_job[pt];
@@ -258,31 +267,70 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             continue;
         }
 
-        // ---- template: bilinear samples of I (x32) and of the Scharr gradients ----
+        // ---- stage both regions of this level: their loads are in flight together ----
+        const uint32_t ipitch = a.A.lv[level].img_pitch;
+        const uint8_t* imgI = level_img(a.A, img_I, level);
+        const uint8_t* imgJ = level_img(a.A, img_J, level);
+        nx -= half_x; ny -= half_y;
+        const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
+        const Region RI = stage_region<I_ROWS>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane);
+        Region R;
+        R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
+        if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h))
+            R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane);
+        lds_fence();
+
+        // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
         int Iw[SEGLEN];
         int Gx[SEGLEN], Gy[SEGLEN];
-        const uint32_t ipitch = a.A.lv[level].img_pitch, gpitch = a.A.lv[level].grad_pitch;
         float A11, A12, A22;
         {
             const BilinW bw = bilin_weights(px - ipx, py - ipy);
-            const uint8_t* imgI = level_img(a.A, img_I, level);
-            const uint8_t* grdI = level_grad(a.A, img_I, level);
-            const bool interior = ipx >= 0 && ipy >= 0 && ipx + ext_w < w && ipy + wh < h;
-            int r0[SEGLEN + 1], r1[SEGLEN + 1];
-            load_row_u8<SEGLEN>(imgI, ipitch, w, h, ipx + x0, ipy + rc, interior, r0);
-            load_row_u8<SEGLEN>(imgI, ipitch, w, h, ipx + x0, ipy + rc + 1, interior, r1);
-            int gx0r[SEGLEN + 1], gy0r[SEGLEN + 1], gx1r[SEGLEN + 1], gy1r[SEGLEN + 1];
-            load_row_grad<SEGLEN>(grdI, gpitch, w, h, ipx + x0, ipy + rc, interior, gx0r, gy0r);
-            load_row_grad<SEGLEN>(grdI, gpitch, w, h, ipx + x0, ipy + rc + 1, interior, gx1r, gy1r);
+            // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2.
+            // Rows are consumed one at a time (rolling three-row window) and folded into the weighted sums at once.
+            const int boff = ipx + x0 - 1 - RI.rx0;             // columns ipx+x0-1 .. ipx+x0+SEGLEN+1
+            int ra[SEGLEN + 3], rb[SEGLEN + 3], rcw[SEGLEN + 3];
+            read_row_bytes<SEGLEN + 3>(ilds, rc, boff, ra);
+            read_row_bytes<SEGLEN + 3>(ilds, rc + 1, boff, rb);
+            int sI[SEGLEN], sX[SEGLEN], sY[SEGLEN];
+#pragma unroll
+            for (int k = 0; k < SEGLEN; k++) { sI[k] = rb[k + 1] * bw.w00 + rb[k + 2] * bw.w01; sX[k] = 0; sY[k] = 0; }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                read_row_bytes<SEGLEN + 3>(ilds, rc + 2 + j, boff, rcw);
+                const int wl = j == 0 ? bw.w00 : bw.w10, wr = j == 0 ? bw.w01 : bw.w11;
+                const int gy = ipy + rc + j;
+                const bool row_in = gy >= 0 && gy < h;
+                if (j == 1) {
+#pragma unroll
+                    for (int k = 0; k < SEGLEN; k++) sI[k] += rb[k + 1] * bw.w10 + rb[k + 2] * bw.w11;
+                }
+                int t0p = 0, t1p = 0, t0c = 0, t1c = 0;   // vertical sums of the two previous columns
+#pragma unroll
+                for (int c = 0; c < SEGLEN + 3; c++) {
+                    const int t0 = (ra[c] + rcw[c]) * 3 + rb[c] * 10;
+                    const int t1 = rcw[c] - ra[c];
+                    if (c >= 2) {
+                        const int k = c - 2;                    // sample column ipx + x0 + k
+                        const int gxp = ipx + x0 + k;
+                        const bool in = row_in && gxp >= 0 && gxp < w;
+                        const int ix = in ? t0 - t0p : 0;                       // zero outside the image
+                        const int iy = in ? (t1 + t1p) * 3 + t1c * 10 : 0;
+                        if (k < SEGLEN) { sX[k] += ix * wl; sY[k] += iy * wl; }
+                        if (k > 0) { sX[k - 1] += ix * wr; sY[k - 1] += iy * wr; }
+                    }
+                    t0p = t0c; t1p = t1c; t0c = t0; t1c = t1;
+                }
+#pragma unroll
+                for (int c = 0; c < SEGLEN + 3; c++) { ra[c] = rb[c]; rb[c] = rcw[c]; }
+            }
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int k = 0; k < SEGLEN; k++) {
                 const bool ok = row_ok && (x0 + k < ww);
-                const int iv = descale(r0[k] * bw.w00 + r0[k + 1] * bw.w01 + r1[k] * bw.w10 + r1[k + 1] * bw.w11, 9);
-                int ix = descale(gx0r[k] * bw.w00 + gx0r[k + 1] * bw.w01 + gx1r[k] * bw.w10 + gx1r[k + 1] * bw.w11, 14);
-                int iy = descale(gy0r[k] * bw.w00 + gy0r[k + 1] * bw.w01 + gy1r[k] * bw.w10 + gy1r[k + 1] * bw.w11, 14);
-                if (!ok) { ix = 0; iy = 0; }
-                Iw[k] = iv; Gx[k] = ix; Gy[k] = iy;
+                const int ix = ok ? descale(sX[k], 14) : 0;
+                const int iy = ok ? descale(sY[k], 14) : 0;
+                Iw[k] = descale(sI[k], 9); Gx[k] = ix; Gy[k] = iy;
                 a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
             }
             A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
@@ -300,12 +348,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         D = 1.f / D;
 
         // ---- Newton iterations on the target image, fed from LDS ----
-        const uint8_t* imgJ = level_img(a.A, img_J, level);
-        nx -= half_x; ny -= half_y;
         float pdx = 0.f, pdy = 0.f;
         n_iter = 0;
-        JRegion R;
-        R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
         for (int j = 0; j < a.max_iter; j++) {
             const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
             if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
@@ -313,7 +357,10 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 break;
             }
             n_iter = j + 1;
-            if (!region_holds(R, inx, iny, ext_w, wh)) R = stage_region(jlds, imgJ, ipitch, w, h, inx, iny, ext_w, wh, lane);
+            if (!region_holds(R, inx, iny, ext_w, wh)) {
+                R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane);
+                lds_fence();
+            }
             const BilinW jw = bilin_weights(nx - inx, ny - iny);
             const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
             uint32_t p0[SEGLEN], p1[SEGLEN];
@@ -349,7 +396,10 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
                 st = 0;
             } else {
-                if (!region_holds(R, iqx, iqy, ext_w, wh)) R = stage_region(jlds, imgJ, ipitch, w, h, iqx, iqy, ext_w, wh, lane);
+                if (!region_holds(R, iqx, iqy, ext_w, wh)) {
+                    R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane);
+                    lds_fence();
+                }
                 const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
                 const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
                 uint32_t p0[SEGLEN], p1[SEGLEN];

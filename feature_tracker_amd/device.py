@@ -47,7 +47,8 @@ class ft_keypoint(C.Structure):
 
 class ft_kernel_time(C.Structure):
     _fields_ = [("pyramid_ms", C.c_double), ("pyramid_launches", C.c_int), ("lk_ms", C.c_double), ("lk_launches", C.c_int),
-                ("fast_ms", C.c_double), ("fast_launches", C.c_int)]
+                ("fast_ms", C.c_double), ("fast_launches", C.c_int),
+                ("lk_points", C.c_longlong), ("lk_level_visits", C.c_longlong), ("lk_iterations", C.c_longlong)]
 
 
 # every symbol include/ft_device.h declares

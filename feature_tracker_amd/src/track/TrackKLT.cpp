@@ -188,7 +188,7 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
     mono_begin(timestamp, img.cols, img.rows, cam_id, plan);
     if (be->upload(plan.stream, plan.slot_cur, img.data, img.cols, img.rows, img.step) != FT_OK) return;
     const ft_lk_params prm = lk_params();
-    if (be->build_pyramid(1, &plan.stream, &plan.slot_cur, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+    if (be->build_pyramid(1, &plan.stream, &plan.slot_cur, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
 
     const int cells = Grider_FAST::cells_for(img.cols, img.rows, grid_x, grid_y);
     const int kmax = per_cell_max();
@@ -355,10 +355,10 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     if (be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
     const int streams[2] = {sl, sr}, slots[2] = {cur_l, cur_r};
     if (img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows) {
-        if (be->build_pyramid(2, streams, slots, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+        if (be->build_pyramid(2, streams, slots, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
     } else {
-        if (be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
-        if (be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 1, nullptr) != FT_OK) return;
+        if (be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
+        if (be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
     }
     const DeviceImage cur_left{be, sl, cur_l, img_leftin.cols, img_leftin.rows};
     const DeviceImage cur_right{be, sr, cur_r, img_rightin.cols, img_rightin.rows};

@@ -46,7 +46,24 @@ public:
     void flush_db() {
         if (!db_pending) return;
         db_pending = false;
-        pool->parallel_for(size(), [&](int s) { trackers[s]->mono_commit(db_plans[s]); });
+        commit_db(db_plans);
+    }
+    // hand the pending observations to the caller instead (e.g. to a writer thread); returns false if there are none
+    bool take_db(std::vector<TrackKLT::MonoPlan>& out) {
+        if (!db_pending) return false;
+        db_pending = false;
+        out.resize(db_plans.size());
+        for (size_t s = 0; s < db_plans.size(); s++) {
+            out[s].db_ids.swap(db_plans[s].db_ids); out[s].db_uvn.swap(db_plans[s].db_uvn);
+            out[s].timestamp = db_plans[s].timestamp; out[s].cam = db_plans[s].cam; out[s].db_pending = db_plans[s].db_pending;
+            db_plans[s].db_pending = false;
+        }
+        return true;
+    }
+    // apply observations taken with take_db; touches only the feature databases, which carry their own locks, so it
+    // may run on another thread than begin()/complete() as long as one stream's sets are applied in order
+    void commit_db(std::vector<TrackKLT::MonoPlan>& payload) {
+        pool->parallel_for((int)payload.size(), [&](int s) { trackers[s]->mono_commit(payload[s]); });
     }
     bool in_flight() const { return pending; }
 
@@ -88,7 +105,7 @@ public:
             }
         }
         lap(ST_INGEST);
-        if ((rc = be->build_pyramid(S, streams.data(), cur_slots.data(), t0.max_level(), t0.window(), t0.window(), 1, nullptr)) != FT_OK) return rc;
+        if ((rc = be->build_pyramid(S, streams.data(), cur_slots.data(), t0.max_level(), t0.window(), t0.window(), 0, nullptr)) != FT_OK) return rc;
 
         lap(ST_PYRAMID);
         // detections of the previous frames: cached (speculative) or computed now for the streams that need them

@@ -3,7 +3,7 @@
  *
  * This is the boundary the reference would bind in place of its three OpenCV entry points and cv::FAST:
  *   cv::buildOpticalFlowPyramid   src/track/TrackKLT.cpp:51-56      -> ft_build_pyramid
- *   calcSharrDeriv (inside LK)    src/track/TrackKLT.cpp:306,:402   -> ft_build_pyramid(with_gradients) / ft_build_gradients
+ *   calcSharrDeriv (inside LK)    src/track/TrackKLT.cpp:306,:402   -> inside ft_lk_track; as images: ft_build_pyramid(with_gradients) / ft_build_gradients
  *   cv::calcOpticalFlowPyrLK      src/track/TrackKLT.cpp:306,:402   -> ft_lk_track
  *   cv::FAST + sort + top-k       src/track/Grider_FAST.h:94-130    -> ft_fast_grid
  *   K*R*K^-1 point warp           src/track/TrackMsckfVio.cpp:348-355 (commented sketch) -> ft_lk_job::H / ft_predict_flow
@@ -69,8 +69,8 @@ typedef struct ft_lk_params {
 
 /* One LK job = one calcOpticalFlowPyrLK call of the reference (one image pair, n points). */
 typedef struct ft_lk_job {
-    int stream_prev, slot_prev;   /* template pyramid; needs gradients */
-    int stream_next, slot_next;   /* target pyramid (needs gradients too when FT_LK_FORWARD_BACKWARD is set) */
+    int stream_prev, slot_prev;   /* template pyramid (its Scharr gradients are evaluated inside the kernel) */
+    int stream_next, slot_next;   /* target pyramid */
     int n;                        /* number of points */
     const float* prev_xy;         /* n*2, level-0 pixels */
     float* next_xy;               /* n*2, in: initial guess (FT_LK_USE_INITIAL_FLOW and H == NULL), out: result */
@@ -90,6 +90,9 @@ typedef struct ft_kernel_time {
     double pyramid_ms;   int pyramid_launches;    /* fused pyrDown + Scharr level kernel */
     double lk_ms;        int lk_launches;
     double fast_ms;      int fast_launches;       /* score + nms/compact + top-k, per ft_fast_grid call */
+    /* LK work done while profiling: points tracked, (point, level) pairs whose template was evaluated, and Newton
+     * iterations summed over them (from the kernel's own per-level counters) */
+    long long lk_points, lk_level_visits, lk_iterations;
 } ft_kernel_time;
 
 int ft_ctx_create(ft_ctx** out, int device, const ft_limits* limits);

@@ -95,7 +95,7 @@ def test_lk_matches_oracle(dev, win, max_level, shape, n):
     with _ctx(dev, w, h) as ctx:
         ctx.upload(0, 0, prev)
         ctx.upload(0, 1, nxt)
-        ctx.build_pyramid([0, 0], [0, 1], max_level, win)
+        ctx.build_pyramid([0, 0], [0, 1], max_level, win, with_gradients=False)   # LK evaluates Scharr itself
         out = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=max_level), want_iters=True)[0]
     _compare_lk(out, ref)
     assert np.array_equal(out[3], ref[3])          # identical iteration counts per level
@@ -215,7 +215,9 @@ def test_error_codes(dev):
             ctx.upload(5, 0, np.zeros((96, 128), np.uint8))
         assert e.value.code == -1
         ctx.upload(0, 0, np.zeros((96, 128), np.uint8))
-        ctx.build_pyramid([0], [0], 2, 15, with_gradients=False)
-        with pytest.raises(dev.FtError) as e:            # gradients missing
-            ctx.lk_track([dict(prev=(0, 0), next=(0, 0), prev_xy=np.zeros((4, 2), np.float32))], dev.LKParams(win=15, max_level=2))
+        with pytest.raises(dev.FtError) as e:            # gradient images were never built
+            ctx.download_grad(0, 0, 0)
         assert e.value.code == -5
+        with pytest.raises(dev.FtError) as e:            # window larger than the kernel supports
+            ctx.lk_track([dict(prev=(0, 0), next=(0, 0), prev_xy=np.zeros((4, 2), np.float32))], dev.LKParams(win=41, max_level=2))
+        assert e.value.code == -1
