@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--groups", type=int, default=0, help="stream groups per GPU (0 = library default)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per GPU (0 = library default)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="feed frames from host memory (PCIe-inclusive rate; not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -180,7 +182,10 @@ def main():
     tracked = attempted = 0
     for i in range(W + 1, W + 1 + K):
         # software-pipelined feed: the last stream group's frame completes during the next call (or in flush below)
-        tr, at = b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
+        if args.host_frames:
+            tr, at = b.feed_host(stamps[i], [q.frames[i] for q in seqs], pipelined=True)
+        else:
+            tr, at = b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
         tracked += tr
         attempted += at
     tr, at = b.flush()
@@ -245,7 +250,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/i16 images, i32 exact sums, f32 solve", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": S, "width": w, "height": h,
                        "features_per_stream": wl["opts"]["num_pts"], "window": wl["opts"]["win_size"],
-                       "max_level": wl["opts"]["pyr_levels"], "frames_in_hbm": True},
+                       "max_level": wl["opts"]["pyr_levels"], "frames_in_hbm": not args.host_frames},
             "tracked_fraction": tracked_all / max(1.0, attempted_all),
             "frames_per_sec": world * S * K / dt_max,
             "roofline": roofline,

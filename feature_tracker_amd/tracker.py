@@ -182,13 +182,14 @@ class BatchTracker(_Base):
         a, w = np.ascontiguousarray(am, dtype=np.float64), np.ascontiguousarray(wm, dtype=np.float64)
         self._check(self.lib.ftk_batch_feed_imu(self._h, stream, t, _dp(a), _dp(w)), "batch_feed_imu")
 
-    def feed_host(self, timestamps, frames):
-        """frames: sequence of n (h, w) uint8 arrays."""
+    def feed_host(self, timestamps, frames, pipelined=False):
+        """frames: sequence of n (h, w) uint8 arrays (copied into pinned staging during the call)."""
         keep = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
         h, w = keep[0].shape
         for i, f in enumerate(keep):
             self._ptrs[i] = f.ctypes.data
-        return self._feed(timestamps, 0, w, h, keep[0].strides[0])
+        self._keep_prev, self._keep = getattr(self, "_keep", None), keep   # a pipelined set completes one call later
+        return self._feed(timestamps, 0, w, h, keep[0].strides[0], pipelined)
 
     def feed_device(self, timestamps, dev_ptrs, w, h, stride, pipelined=False):
         """dev_ptrs: n device addresses of frames resident in HBM.  pipelined=True leaves the last group's frame in

@@ -54,10 +54,10 @@ int ftk_tracker_database_size(ftk_tracker* t);
 int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
 
 /* ---- n independent monocular streams, batched ----
- * The streams are split into `n_groups` groups (0 = choose: 4 from 32 streams, 2 from 8, else 1).  A group has its own
- * device context and queue and its own host driver thread, so groups overlap each other's device work and host
- * bookkeeping.  host_threads (0 = choose, at most 8) is the total number of host threads: one driver per group, the
- * rest help with the per-stream bookkeeping inside the groups. */
+ * The streams are split into `n_groups` groups (0 = choose: 2 from 8 streams on, else 1).  A group has its own device
+ * context and queue, a host driver thread and a feature-database writer thread, so groups overlap each other's device
+ * work and host bookkeeping.  host_threads (0 = choose: two per group) is the total number of host threads; threads
+ * beyond two per group help with the per-stream bookkeeping inside the groups. */
 int ftk_batch_create(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height);
 int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, int n_streams, int max_width, int max_height,
                              int n_groups, int host_threads);
