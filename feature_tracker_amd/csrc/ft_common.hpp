@@ -30,6 +30,16 @@ struct ImgList {
 
 __host__ __device__ inline int half_up(int v) { return (v + 1) >> 1; }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A launch over a linear work list of `total`
+// items uses xcd_grid(total) workgroups and workgroup b handles item xcd_item(b, total) (or nothing if that is
+// >= total): every XCD then walks one contiguous eighth of the list, so tiles that share image lines (neighbours in
+// the list) meet in one L2 instead of being fetched from memory once per XCD.  Only speed depends on the dealing
+// order; any order gives the same result.
+constexpr int XCDS = 8;
+__host__ __device__ inline int xcd_share(int total) { return (total + XCDS - 1) / XCDS; }
+__host__ inline int xcd_grid(int total) { return xcd_share(total) * XCDS; }
+__device__ inline int xcd_item(int block, int total) { return (block % XCDS) * xcd_share(total) + block / XCDS; }
+
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ inline int reflect101(int p, int len) {
     if (len == 1) return 0;

@@ -38,6 +38,7 @@ struct EventPair {
 
 struct PendingLK {
     bool active = false;
+    uint64_t seq = 0;          // position in the queue (see ft_ctx::seq)
     std::vector<ft_lk_job> jobs;
     int total = 0;
     int nlev = 0;
@@ -47,6 +48,7 @@ struct PendingLK {
 
 struct PendingFast {
     bool active = false;
+    uint64_t seq = 0;
     int n = 0, cells = 0, per_cell = 0, cap = 0;
     ft_keypoint* out = nullptr;
     int* n_out = nullptr;
@@ -77,10 +79,20 @@ struct ft_ctx {
     // FAST scratch
     uint32_t* cand = nullptr; size_t cand_entries_per_img = 0;
     int* cand_count = nullptr;          // [n_streams][max_grid_cells]
-    ft_keypoint* kp_dev = nullptr;      // [n_streams][max_grid_cells][max_per_cell]
-    int* kp_count_dev = nullptr;        // [n_streams][max_grid_cells]
-    uint8_t* fast_out_host = nullptr; size_t fast_out_bytes = 0;
-    PendingFast fast_pending;
+    uint8_t* fast_out_dev = nullptr;    // one block per call: keypoints, kept counts, survivor counts (one D2H copy)
+    // detector outputs are double-buffered on the host side so that the detector of the next frame set can be
+    // enqueued before the previous set's outputs have been delivered
+    static constexpr int FAST_RING = 2;
+    uint8_t* fast_out_host[FAST_RING] = {nullptr, nullptr}; size_t fast_out_bytes = 0;
+    PendingFast fast_pending[FAST_RING];
+    int fast_next = 0;
+
+    // every *_async call takes the next sequence number; a fence remembers the number reached when it was recorded
+    uint64_t seq = 0;
+    static constexpr int FENCE_RING = 16;
+    struct Fence { hipEvent_t ev = nullptr; uint64_t id = 0, seq = 0; };
+    Fence fences[FENCE_RING];
+    uint64_t fence_ids = 0;
 
     // small device scratch for ft_predict_flow
     float* pf_dev = nullptr; float* pf_host = nullptr; size_t pf_points = 0;
@@ -124,7 +136,9 @@ void prof_end(ft_ctx* c, EventPair& ep) {
     c->ev_inflight.push_back(ep);
 }
 void prof_collect(ft_ctx* c) {
+    size_t kept = 0;
     for (auto& ep : c->ev_inflight) {
+        if (hipEventQuery(ep.b) == hipErrorNotReady) { c->ev_inflight[kept++] = ep; continue; }   // still queued
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             if (ep.kind == 0) { c->times.pyramid_ms += ms; c->times.pyramid_launches++; }
@@ -133,7 +147,7 @@ void prof_collect(ft_ctx* c) {
         }
         c->ev_pool.push_back(ep);
     }
-    c->ev_inflight.clear();
+    c->ev_inflight.resize(kept);
 }
 
 // number of the top level buildOpticalFlowPyramid would produce (early stop when the next level <= window)
@@ -146,9 +160,33 @@ int achieved_level(int w, int h, int win_w, int win_h, int max_level) {
     return max_level;
 }
 
-int deliver_pending(ft_ctx* c) {
-    // called after the queue has drained
-    if (c->lk_pending.active) {
+void deliver_fast(ft_ctx* c, PendingFast& F, const uint8_t* host) {
+    const size_t per_img = (size_t)F.cells * F.per_cell;
+    const ft_keypoint* kp = reinterpret_cast<const ft_keypoint*>(host);
+    const int* cnt = reinterpret_cast<const int*>(host + align_up(sizeof(ft_keypoint) * per_img * F.n, 16));
+    const int* ccnt = cnt + (size_t)F.n * F.cells;
+    for (int i = 0; i < F.n; i++) {
+        int m = 0;
+        for (int cell = 0; cell < F.cells; cell++) {
+            const int k = cnt[(size_t)i * F.cells + cell];
+            const ft_keypoint* src = kp + (size_t)i * per_img + (size_t)cell * F.per_cell;
+            for (int r = 0; r < k && m < F.cap; r++) F.out[(size_t)i * F.cap + m++] = src[r];
+        }
+        if (F.n_out) F.n_out[i] = m;
+        if (F.cell_counts) memcpy(F.cell_counts + (size_t)i * F.cells, ccnt + (size_t)i * F.cells, sizeof(int) * F.cells);
+    }
+    F.active = false;
+}
+
+// outputs of every *_async call with sequence number <= upto; the queue must have passed them
+int deliver_pending(ft_ctx* c, uint64_t upto) {
+    // detector results in enqueue order (the older ring entry first)
+    for (int k = 0; k < ft_ctx::FAST_RING; k++) {
+        const int i = (c->fast_next + k) % ft_ctx::FAST_RING;
+        PendingFast& F = c->fast_pending[i];
+        if (F.active && F.seq <= upto) deliver_fast(c, F, c->fast_out_host[i]);
+    }
+    if (c->lk_pending.active && c->lk_pending.seq <= upto) {
         PendingLK& P = c->lk_pending;
         const size_t N = (size_t)P.total;
         const float* xy = reinterpret_cast<const float*>(c->lk_out_host);
@@ -173,24 +211,6 @@ int deliver_pending(ft_ctx* c) {
         }
         P.active = false;
     }
-    if (c->fast_pending.active) {
-        PendingFast& F = c->fast_pending;
-        const size_t per_img = (size_t)F.cells * F.per_cell;
-        const ft_keypoint* kp = reinterpret_cast<const ft_keypoint*>(c->fast_out_host);
-        const int* cnt = reinterpret_cast<const int*>(c->fast_out_host + align_up(sizeof(ft_keypoint) * per_img * F.n, 16));
-        const int* ccnt = cnt + (size_t)F.n * F.cells;
-        for (int i = 0; i < F.n; i++) {
-            int m = 0;
-            for (int cell = 0; cell < F.cells; cell++) {
-                const int k = cnt[(size_t)i * F.cells + cell];
-                const ft_keypoint* src = kp + (size_t)i * per_img + (size_t)cell * F.per_cell;
-                for (int r = 0; r < k && m < F.cap; r++) F.out[(size_t)i * F.cap + m++] = src[r];
-            }
-            if (F.n_out) F.n_out[i] = m;
-            if (F.cell_counts) memcpy(F.cell_counts + (size_t)i * F.cells, ccnt + (size_t)i * F.cells, sizeof(int) * F.cells);
-        }
-        F.active = false;
-    }
     return FT_OK;
 }
 
@@ -198,7 +218,7 @@ int sync_and_deliver(ft_ctx* c) {
     FT_HIP(c, hipStreamSynchronize(c->q));
     std::fill(c->stage_busy.begin(), c->stage_busy.end(), 0);
     prof_collect(c);
-    return deliver_pending(c);
+    return deliver_pending(c, ~0ull);
 }
 
 int pick_seglen(int win_w, int win_h) {
@@ -233,8 +253,8 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
         const int do_down = (down && l < top) ? 1 : 0;
         const int do_grad = grad ? 1 : 0;
         if (do_down || do_grad) {
-            dim3 grid((lw + LV_TX - 1) / LV_TX, (lh + LV_TY - 1) / LV_TY, L.n);
-            hipLaunchKernelGGL(level_kernel, grid, dim3(256), 0, c->q, c->arena, L, l, lw, lh, do_grad, do_down);
+            const int tiles = ((lw + LV_TX - 1) / LV_TX) * ((lh + LV_TY - 1) / LV_TY);
+            hipLaunchKernelGGL(level_kernel, dim3(xcd_grid(tiles * L.n)), dim3(256), 0, c->q, c->arena, L, l, lw, lh, do_grad, do_down);
         }
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
     }
@@ -245,8 +265,8 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
 
 template <int SEGLEN>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
-    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(total), dim3(64), 0, c->q, a);
-    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(total), dim3(64), 0, c->q, a);
+    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(64), 0, c->q, a);
+    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(64), 0, c->q, a);
 }
 
 }  // namespace
@@ -336,14 +356,19 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     if (hipMalloc(&p, sizeof(uint32_t) * c->cand_entries_per_img * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
     c->cand = (uint32_t*)p;
     const size_t cells_total = (size_t)lim->n_streams * lim->max_grid_cells;
-    if (hipMalloc(&p, sizeof(int) * cells_total * 2) != hipSuccess) return fail(FT_E_NOMEM);
+    if (hipMalloc(&p, sizeof(int) * cells_total) != hipSuccess) return fail(FT_E_NOMEM);
     c->cand_count = (int*)p;
-    c->kp_count_dev = c->cand_count + cells_total;
-    if (hipMalloc(&p, sizeof(ft_keypoint) * cells_total * lim->max_per_cell) != hipSuccess) return fail(FT_E_NOMEM);
-    c->kp_dev = (ft_keypoint*)p;
+    // the per-cell candidate counters start at zero and every top-k pass leaves them at zero again
+    if (hipMemset(c->cand_count, 0, sizeof(int) * cells_total) != hipSuccess) return fail(FT_E_HIP);
     c->fast_out_bytes = align_up(sizeof(ft_keypoint) * cells_total * lim->max_per_cell, 16) + sizeof(int) * cells_total * 2 + 256;
-    if (hipHostMalloc(&p, c->fast_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
-    c->fast_out_host = (uint8_t*)p;
+    if (hipMalloc(&p, c->fast_out_bytes) != hipSuccess) return fail(FT_E_NOMEM);
+    c->fast_out_dev = (uint8_t*)p;
+    for (int i = 0; i < ft_ctx::FAST_RING; i++) {
+        if (hipHostMalloc(&p, c->fast_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+        c->fast_out_host[i] = (uint8_t*)p;
+    }
+    for (auto& f : c->fences)
+        if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) return fail(FT_E_HIP);
 
     c->pf_points = N;
     if (hipMalloc(&p, sizeof(float) * (4 * N + 16)) != hipSuccess) return fail(FT_E_NOMEM);
@@ -373,8 +398,9 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->cand) (void)hipFree(c->cand);
     if (c->cand_count) (void)hipFree(c->cand_count);
-    if (c->kp_dev) (void)hipFree(c->kp_dev);
-    if (c->fast_out_host) (void)hipHostFree(c->fast_out_host);
+    if (c->fast_out_dev) (void)hipFree(c->fast_out_dev);
+    for (auto& h : c->fast_out_host) if (h) (void)hipHostFree(h);
+    for (auto& f : c->fences) if (f.ev) (void)hipEventDestroy(f.ev);
     if (c->pf_dev) (void)hipFree(c->pf_dev);
     if (c->pf_host) (void)hipHostFree(c->pf_host);
     if (c->q) (void)hipStreamDestroy(c->q);
@@ -533,13 +559,13 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
     a.pt_job = reinterpret_cast<const uint16_t*>(c->lk_in_dev + off_ptjob);
     a.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);
-    // the output block doubles as the in/out next_xy array: seed it with the guesses
+    a.guess_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_next);
     uint8_t* ob = c->lk_out_dev;
-    FT_HIP(c, hipMemcpyAsync(ob, c->lk_in_dev + off_next, 8 * N, hipMemcpyDeviceToDevice, c->q));
     a.next_xy = reinterpret_cast<float*>(ob);
     a.err = reinterpret_cast<float*>(ob + 8 * N);
     a.status = ob + 12 * N;
     a.iters = want_iters ? reinterpret_cast<int*>(ob + align_up(13 * N, 16)) : nullptr;
+    a.total = (int)N;
     a.nlev = nlev;
     a.win_w = prm->win_w; a.win_h = prm->win_h;
     a.segs = (prm->win_w + seglen - 1) / seglen;
@@ -573,6 +599,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     PendingLK& P = c->lk_pending;
     P.jobs.assign(jobs, jobs + n_jobs);
     P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.count_work = c->profile; P.active = true;
+    P.seq = ++c->seq;
     return FT_OK;
 }
 
@@ -603,28 +630,29 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     const size_t need = (size_t)((G.size_x + 1) / 2) * ((G.size_y + 1) / 2);
     G.cand_cap = (int)std::min(need, c->cand_entries_per_img / (size_t)cells);
     FT_HIP(c, hipSetDevice(c->device));
-    if (c->fast_pending.active) {
+    const int ring = c->fast_next;
+    if (c->fast_pending[ring].active) {   // both host buffers hold undelivered results: finish the queue first
         rc = sync_and_deliver(c);
         if (rc) return rc;
     }
-    FT_HIP(c, hipMemsetAsync(c->cand_count, 0, sizeof(int) * (size_t)n * cells, c->q));
+    const size_t kp_bytes = sizeof(ft_keypoint) * (size_t)n * cells * per_cell;
+    const size_t cnt_off = align_up(kp_bytes, 16);
+    ft_keypoint* kp_dev = reinterpret_cast<ft_keypoint*>(c->fast_out_dev);
+    int* kept_dev = reinterpret_cast<int*>(c->fast_out_dev + cnt_off);
+    int* surv_dev = kept_dev + (size_t)n * cells;
     EventPair ep;
     prof_begin(c, 2, ep);
-    dim3 grid((w + FD_TX - 1) / FD_TX, (h + FD_TY - 1) / FD_TY, n);
-    hipLaunchKernelGGL(fast_detect_kernel, grid, dim3(256), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
-    hipLaunchKernelGGL(fast_topk_kernel, dim3(n * cells), dim3(256), 0, c->q, G, c->cand, c->cand_count, c->kp_dev, c->kp_count_dev);
+    const int tiles = ((w + FD_TX - 1) / FD_TX) * ((h + FD_TY - 1) / FD_TY);
+    hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(256), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3(n * cells), dim3(256), 0, c->q, G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev);
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
-    // note: cand is indexed [image*cells + cell][cand_cap], kp_dev [image*cells + cell][per_cell]
-    const size_t kp_bytes = sizeof(ft_keypoint) * (size_t)n * cells * per_cell;
-    uint8_t* hb = c->fast_out_host;
-    FT_HIP(c, hipMemcpyAsync(hb, c->kp_dev, kp_bytes, hipMemcpyDeviceToHost, c->q));
-    int* cnt_h = reinterpret_cast<int*>(hb + align_up(kp_bytes, 16));
-    FT_HIP(c, hipMemcpyAsync(cnt_h, c->kp_count_dev, sizeof(int) * (size_t)n * cells, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipMemcpyAsync(cnt_h + (size_t)n * cells, c->cand_count, sizeof(int) * (size_t)n * cells, hipMemcpyDeviceToHost, c->q));
-    PendingFast& F = c->fast_pending;
-    F.active = true; F.n = n; F.cells = cells; F.per_cell = per_cell; F.cap = cap;
+    // cand is indexed [image*cells + cell][cand_cap], the keypoints [image*cells + cell][per_cell]
+    FT_HIP(c, hipMemcpyAsync(c->fast_out_host[ring], c->fast_out_dev, cnt_off + sizeof(int) * 2 * (size_t)n * cells, hipMemcpyDeviceToHost, c->q));
+    PendingFast& F = c->fast_pending[ring];
+    F.active = true; F.seq = ++c->seq; F.n = n; F.cells = cells; F.per_cell = per_cell; F.cap = cap;
     F.out = out; F.n_out = n_out; F.cell_counts = cell_counts;
+    c->fast_next = (ring + 1) % ft_ctx::FAST_RING;
     return FT_OK;
 }
 
@@ -713,6 +741,28 @@ int ft_sync(ft_ctx* c) {
     if (!c) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
     return sync_and_deliver(c);
+}
+
+int ft_fence(ft_ctx* c, uint64_t* token) {
+    if (!c || !token) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    const uint64_t id = ++c->fence_ids;
+    ft_ctx::Fence& f = c->fences[id % ft_ctx::FENCE_RING];
+    FT_HIP(c, hipEventRecord(f.ev, c->q));
+    f.id = id;
+    f.seq = c->seq;
+    *token = id;
+    return FT_OK;
+}
+
+int ft_wait(ft_ctx* c, uint64_t token) {
+    if (!c) return FT_E_INVALID;
+    ft_ctx::Fence& f = c->fences[token % ft_ctx::FENCE_RING];
+    if (token == 0 || f.id != token) return FT_E_INVALID;   // never issued, or its ring entry was reused
+    FT_HIP(c, hipSetDevice(c->device));
+    FT_HIP(c, hipEventSynchronize(f.ev));
+    prof_collect(c);
+    return deliver_pending(c, f.seq);
 }
 
 int ft_profile(ft_ctx* c, int enable) {

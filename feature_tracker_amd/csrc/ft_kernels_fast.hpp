@@ -64,8 +64,13 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     __shared__ uint8_t col_ok[FD_SW], row_ok[FD_SH];   // column / row lies in the inset of some cell
     __shared__ int list_n;
     const int t = threadIdx.x;
-    const int slot = L.idx[blockIdx.z];
-    const int X0 = blockIdx.x * FD_TX, Y0 = blockIdx.y * FD_TY;
+    // work list: (image, tile row, tile column), images outermost
+    const int tiles_x = (G.w + FD_TX - 1) / FD_TX, tiles_y = (G.h + FD_TY - 1) / FD_TY;
+    const int item = xcd_item(blockIdx.x, tiles_x * tiles_y * L.n);
+    if (item >= tiles_x * tiles_y * L.n) return;
+    const int img_i = item / (tiles_x * tiles_y), tile_i = item - img_i * (tiles_x * tiles_y);
+    const int slot = L.idx[img_i];
+    const int X0 = (tile_i % tiles_x) * FD_TX, Y0 = (tile_i / tiles_x) * FD_TY;
     const uint8_t* __restrict__ img = level_img(A, slot, 0);
     const uint32_t pitch = A.lv[0].img_pitch;
 
@@ -134,20 +139,22 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
             s > q[FD_SPITCH - 1] && s > q[FD_SPITCH] && s > q[FD_SPITCH + 1]) {
             const int gx = X0 + ox, gy = Y0 + oy;
             const int cxi = gx / G.size_x, cyi = gy / G.size_y;
-            const int gcell = blockIdx.z * cells + cyi * G.ct_cols + cxi;
+            const int gcell = img_i * cells + cyi * G.ct_cols + cxi;
             const int at = atomicAdd(&cand_count[gcell], 1);
             if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
         }
     }
 }
 
-// one workgroup per (image, cell): repeated "largest key below the previous one"
-__global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32_t* __restrict__ cand, const int* __restrict__ cand_count,
-                                                       ft_keypoint* __restrict__ out, int* __restrict__ out_count) {
+// one workgroup per (image, cell): repeated "largest key below the previous one".  Also reports the number of NMS
+// survivors of the cell and leaves the cell's candidate counter at zero for the next detector pass.
+__global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32_t* __restrict__ cand, int* __restrict__ cand_count,
+                                                       ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count) {
     __shared__ uint32_t red[4];
     const int gcell = blockIdx.x;
     const int cell = gcell % (G.ct_cols * G.ct_rows);
-    const int n = min(cand_count[gcell], G.cand_cap);
+    const int survivors = cand_count[gcell];
+    const int n = min(survivors, G.cand_cap);
     const uint32_t* c = cand + (uint64_t)gcell * G.cand_cap;
     const int keep = min(n, G.per_cell);
     const int cell_x = (cell % G.ct_cols) * G.size_x, cell_y = (cell / G.ct_cols) * G.size_y;
@@ -173,7 +180,12 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32
         }
         bound = best;
     }
-    if (threadIdx.x == 0) out_count[gcell] = keep;
+    __syncthreads();   // every thread has read the counter
+    if (threadIdx.x == 0) {
+        out_count[gcell] = keep;
+        surv_count[gcell] = survivors;
+        cand_count[gcell] = 0;
+    }
 }
 
 }  // namespace ftd

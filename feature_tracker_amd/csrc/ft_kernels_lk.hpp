@@ -31,10 +31,12 @@ struct LKArgs {
     const LKJobDev* jobs;
     const uint16_t* pt_job;   // job index of every point
     const float* prev_xy;     // template points (forward) / original points (backward)
-    float* next_xy;           // forward: in = guess, out = result; backward: template points (read only)
+    const float* guess_xy;    // forward: initial guesses (unused for jobs with a homography)
+    float* next_xy;           // forward: results; backward: template points (read only)
     uint8_t* status;
     float* err;
     int* iters;               // optional [n][nlev]
+    int total;                // number of points
     int nlev;                 // levels per iters row
     int win_w, win_h, segs;
     int max_level;            // already clamped to the pyramids
@@ -202,7 +204,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
     __shared__ uint32_t jlds[LK_RH_MAX * LK_RW_DWORDS + 4];         // target region (+ slack: row reads are dword-granular)
     __shared__ uint32_t ilds[(32 + 3) * LK_RW_DWORDS + 4];          // template region: window + Scharr apron
-    const int pt = blockIdx.x;
+    const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
+    if (pt >= a.total) return;
     const int lane = threadIdx.x;
     const LKJobDev* job = a.jobs + a.pt_job[pt];
     const int ww = a.win_w, wh = a.win_h;
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             gx0 = p0 / p2; gy0 = p1 / p2;
             use_init = true;
         } else {
-            gx0 = a.next_xy[2 * pt]; gy0 = a.next_xy[2 * pt + 1];
+            gx0 = a.guess_xy[2 * pt]; gy0 = a.guess_xy[2 * pt + 1];
             use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0;
         }
     } else {

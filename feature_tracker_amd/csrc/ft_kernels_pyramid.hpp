@@ -28,10 +28,15 @@ __device__ inline uint32_t ld_src_dword(const uint8_t* __restrict__ row, int c0,
 
 __global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, int level, int w, int h, int do_grad, int do_down) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[LV_LDS_ROWS * LV_LDS_PITCH];
-    const int slot = L.idx[blockIdx.z];
+    // work list: (image, tile row, tile column), images outermost
+    const int tiles_x = (w + LV_TX - 1) / LV_TX, tiles_y = (h + LV_TY - 1) / LV_TY;
+    const int item = xcd_item(blockIdx.x, tiles_x * tiles_y * L.n);
+    if (item >= tiles_x * tiles_y * L.n) return;
+    const int img_i = item / (tiles_x * tiles_y), tile_i = item - img_i * (tiles_x * tiles_y);
+    const int slot = L.idx[img_i];
     const uint8_t* __restrict__ src = level_img(A, slot, level);
     const uint32_t spitch = A.lv[level].img_pitch;
-    const int X0 = blockIdx.x * LV_TX, Y0 = blockIdx.y * LV_TY;
+    const int X0 = (tile_i % tiles_x) * LV_TX, Y0 = (tile_i / tiles_x) * LV_TY;
     const int t = threadIdx.x;
 
     // ---- stage the tile: 35 rows x 34 dwords ----

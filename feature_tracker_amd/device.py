@@ -54,7 +54,7 @@ class ft_kernel_time(C.Structure):
 # every symbol include/ft_device.h declares
 SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device", "ft_build_pyramid",
            "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_fast_grid", "ft_fast_grid_async",
-           "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync",
+           "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
            "ft_last_hip_error", "ft_device_count"]
 
@@ -109,6 +109,8 @@ def load_library():
     lib.ft_download_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     lib.ft_download_grad.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     lib.ft_sync.argtypes = [vp]
+    lib.ft_fence.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.ft_wait.argtypes = [vp, C.c_uint64]
     lib.ft_profile.argtypes = [vp, C.c_int]
     lib.ft_kernel_times.argtypes = [vp, C.POINTER(ft_kernel_time), C.c_int]
     lib.ft_queue_time_begin.argtypes = [vp]
@@ -298,6 +300,17 @@ class DeviceContext:
     def sync(self):
         self._check(self.lib.ft_sync(self._ctx), "ft_sync")
         self._keep.clear()
+
+    def fence(self):
+        """Mark the current end of the queue; returns a token for wait()."""
+        tok = C.c_uint64()
+        self._check(self.lib.ft_fence(self._ctx, C.byref(tok)), "ft_fence")
+        return tok.value
+
+    def wait(self, token):
+        """Block until the queue has passed the fence and deliver the outputs of the async calls made before it.
+        Output arrays of later async calls are still owned by the library until their own wait or sync()."""
+        self._check(self.lib.ft_wait(self._ctx, C.c_uint64(token)), "ft_wait")
 
     def profile(self, enable):
         self._check(self.lib.ft_profile(self._ctx, int(enable)), "ft_profile")

@@ -34,12 +34,12 @@ FeatureTrackerOptions to_options(const ftk_options& o) {
     return r;
 }
 
-ft_limits limits_for(const ftk_options& o, int n_streams, int w, int h) {
+ft_limits limits_for(const ftk_options& o, int n_streams, int w, int h, int n_slots = 2) {
     ft_limits L;
     L.max_width = w; L.max_height = h;
     L.max_levels = o.pyr_levels + 1;
     L.n_streams = n_streams;
-    L.n_slots = 2;
+    L.n_slots = n_slots;
     L.max_points = n_streams * (o.num_pts + o.grid_x * o.grid_y + 64);
     // a cell can be narrower than cols/grid_x suggests only in degenerate geometry; leave room for that
     L.max_grid_cells = (o.grid_x + 2) * (o.grid_y + 2);
@@ -196,6 +196,12 @@ struct ftk_group {
             }
             Mail& M = mail[next & 1];
             M.rc = batch->begin(M.ts.data(), M.frames.data());
+            // lookahead: if the following set is already in the mailbox, queue its ingest, pyramids and detector now so
+            // that the device stays busy while this set's results are processed
+            if (M.rc == FT_OK && posted.load(std::memory_order_acquire) > next) {
+                Mail& N = mail[(next + 1) & 1];
+                M.rc = batch->stage(N.ts.data(), N.frames.data());
+            }
             if (M.rc == FT_OK) M.rc = batch->complete();
             post_db();   // this set's observations go to the database on the writer thread
             M.tracked = (long long)batch->tracked_features();
@@ -386,9 +392,10 @@ int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, 
             G.first = first;
             G.n = n_streams / n_groups + (g < n_streams % n_groups ? 1 : 0);
             first += G.n;
-            G.be.reset(ftk_make_backend(device, limits_for(*o, G.n, max_width, max_height), &G.device_ctx));
+            // three pyramid slots per stream: previous, current, and the next frame staged while the current is tracked
+            G.be.reset(ftk_make_backend(device, limits_for(*o, G.n, max_width, max_height, 3), &G.device_ctx));
             if (!G.be) return FT_E_NODEVICE;
-            G.batch.reset(new TrackKLTBatch(G.be.get(), to_options(*o), G.n, per_group));
+            G.batch.reset(new TrackKLTBatch(G.be.get(), to_options(*o), G.n, per_group, 3));
         }
         for (auto& g : b->groups) g->start();
         *out = b.release();

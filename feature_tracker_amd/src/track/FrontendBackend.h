@@ -21,6 +21,10 @@ public:
                                 int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts) = 0;
     virtual void homography(const float* K4, const float* R_p_c, float* H) = 0;
     virtual int sync() = 0;
+    // partial wait: fence() marks the end of the queue, wait(token) returns once the queue has passed the mark and the
+    // outputs of the async calls made before it are delivered; later work keeps running
+    virtual int fence(uint64_t* token) = 0;
+    virtual int wait(uint64_t token) = 0;
     virtual const char* name() const = 0;
 };
 

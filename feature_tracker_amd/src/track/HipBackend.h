@@ -36,6 +36,8 @@ public:
     }
     void homography(const float* K4, const float* R_p_c, float* H) override { ft_homography(K4, R_p_c, H); }
     int sync() override { return ft_sync(ctx_); }
+    int fence(uint64_t* token) override { return ft_fence(ctx_, token); }
+    int wait(uint64_t token) override { return ft_wait(ctx_, token); }
     const char* name() const override { return "hip-gfx950"; }
     ft_ctx* ctx() { return ctx_; }
 

@@ -67,7 +67,7 @@ void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, M
     plan.timestamp = timestamp;
     plan.stream = stream0 + (int)cam_id;
     plan.slot_last = cs.slot_last;
-    plan.slot_cur = cs.slot_last == 0 ? 1 : 0;
+    plan.slot_cur = (cs.slot_last + 1) % slot_ring;   // slot_last = -1 before the first frame
     plan.cols = cols; plan.rows = rows;
 }
 

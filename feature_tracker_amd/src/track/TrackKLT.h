@@ -89,6 +89,14 @@ public:
     //    tracking depends on it, so a driver may run it while the device works on the next frame.
     void mono_commit(MonoPlan& plan);
 
+    // depth of the pyramid slot ring the monocular path cycles through (2 = previous + current; a driver that
+    // ingests frame k+1 while frame k is still being tracked needs 3).  The backend must have that many slots.
+    void set_slot_ring(int depth) { slot_ring = depth < 2 ? 2 : depth; }
+    int slot_ring_depth() const { return slot_ring; }
+    // slot the frame after the one described by `plan` will use
+    int slot_after(const MonoPlan& plan) const { return (plan.slot_cur + 1) % slot_ring; }
+    int next_slot(size_t cam_id) { return (cams[cam_id].slot_last + 1) % slot_ring; }
+
     ft_lk_params lk_params() const;
     int per_cell_max() const { return num_features / (grid_x * grid_y) + 1; }
     int grid_cols() const { return grid_x; }
@@ -163,6 +171,7 @@ protected:
     bool forward_backward = false;
     float fb_thresh = 1.0f;
     bool speculative_detect = true;
+    int slot_ring = 2;
 
     // per camera: device slot holding the last pyramid (-1 = none), its size and timestamp
     struct CamState {

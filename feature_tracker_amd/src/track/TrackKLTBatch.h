@@ -5,6 +5,7 @@
 // (src/track/TrackKLT.cpp:51-58, :91-98).
 #pragma once
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -16,9 +17,14 @@ namespace feature_tracker {
 class TrackKLTBatch {
 public:
     // host_threads: threads for the per-stream bookkeeping, the calling thread included (0 = choose, at most 8)
-    TrackKLTBatch(FrontendBackend* backend, const FeatureTrackerOptions& opt, int n_streams, int host_threads = 0)
-        : be(backend), options(opt) {
-        for (int s = 0; s < n_streams; s++) trackers.emplace_back(new TrackKLT(backend, opt, 0, s));
+    // slot_ring: pyramid slots per stream in the backend; from 3 on, stage() may ingest the next frame set while the
+    // current one is still being tracked
+    TrackKLTBatch(FrontendBackend* backend, const FeatureTrackerOptions& opt, int n_streams, int host_threads = 0, int slot_ring = 2)
+        : be(backend), options(opt), ring(slot_ring < 2 ? 2 : slot_ring) {
+        for (int s = 0; s < n_streams; s++) {
+            trackers.emplace_back(new TrackKLT(backend, opt, 0, s));
+            trackers.back()->set_slot_ring(ring);
+        }
         plans.resize(n_streams);
         db_plans.resize(n_streams);
         if (host_threads <= 0) host_threads = default_host_threads(n_streams);
@@ -67,6 +73,25 @@ public:
     }
     bool in_flight() const { return pending; }
 
+    // Optional lookahead between begin() and complete() of the set in flight: enqueue everything of the NEXT frame set
+    // that does not depend on the current set's tracking results (ingest, pyramids, speculative detector), into the
+    // ring slots that set will use.  The device then has work queued while the host finishes the current set, and the
+    // following begin() with the same timestamps and frames finds that part done.  Needs a slot ring of 3.
+    bool can_stage() const { return ring >= 3 && pending && !staged && size() > 0 && trackers[0]->speculative(); }
+    int stage(const double* timestamps, const FrameSource* frames) {
+        if (!can_stage()) return FT_OK;
+        const int S = size();
+        staged_slots.resize(S);
+        for (int s = 0; s < S; s++) staged_slots[s] = trackers[s]->slot_after(plans[s]);
+        staged_det = det_cur ^ 1;
+        const int rc = enqueue_front(timestamps, frames, staged_slots, det[staged_det], true, nullptr);
+        if (rc != FT_OK) return rc;
+        staged_ts.assign(timestamps, timestamps + S);
+        staged_frames.assign(frames, frames + S);
+        staged = true;
+        return FT_OK;
+    }
+
     // first half of feed(): host preparation and every device launch of the frame set; returns without waiting.
     // A driver that owns several batches on separate device contexts overlaps one batch's device work with another
     // batch's host bookkeeping by interleaving begin() and complete() calls.
@@ -86,27 +111,28 @@ public:
         const int cells = Grider_FAST::cells_for(frames[0].cols, frames[0].rows, gx, gy);
         streams.resize(S); cur_slots.resize(S);
         int rc;
-        bool all_dev = true;
         for (int s = 0; s < S; s++) {
             trackers[s]->mono_begin(timestamps[s], frames[s].cols, frames[s].rows, 0, plans[s]);
             streams[s] = plans[s].stream; cur_slots[s] = plans[s].slot_cur;
-            all_dev &= frames[s].dev != nullptr && frames[s].cols == frames[0].cols && frames[s].rows == frames[0].rows && frames[s].step == frames[0].step;
         }
-        if (all_dev) {   // frames already in HBM: one copy launch for the whole batch
-            dev_ptrs.resize(S);
-            for (int s = 0; s < S; s++) dev_ptrs[s] = frames[s].dev;
-            if ((rc = be->set_frames_device(S, streams.data(), cur_slots.data(), dev_ptrs.data(), frames[0].cols, frames[0].rows, frames[0].step)) != FT_OK) return rc;
+        // was this set staged while the previous one was in flight?
+        bool front_done = false;
+        if (staged) {
+            front_done = true;
+            for (int s = 0; s < S && front_done; s++)
+                front_done = staged_ts[s] == timestamps[s] && staged_slots[s] == cur_slots[s] && staged_frames[s].dev == frames[s].dev &&
+                             staged_frames[s].host == frames[s].host && staged_frames[s].cols == frames[s].cols &&
+                             staged_frames[s].rows == frames[s].rows && staged_frames[s].step == frames[s].step;
+            staged = false;
+            // a stale staging only wrote ring slots this set overwrites; its detector output lands in det[staged_det]
+            det_cur = front_done ? staged_det : (staged_det ^ 1);
+        }
+        if (!front_done) {
+            const std::function<void(int)> lap_fn = lap;
+            if ((rc = enqueue_front(timestamps, frames, cur_slots, det[det_cur], t0.speculative(), &lap_fn)) != FT_OK) return rc;
         } else {
-            for (int s = 0; s < S; s++) {
-                const FrameSource& f = frames[s];
-                if (f.dev) rc = be->set_frames_device(1, &streams[s], &cur_slots[s], &f.dev, f.cols, f.rows, f.step);
-                else rc = be->upload(streams[s], cur_slots[s], f.host, f.cols, f.rows, f.step);
-                if (rc != FT_OK) return rc;
-            }
+            lap(ST_INGEST);
         }
-        lap(ST_INGEST);
-        if ((rc = be->build_pyramid(S, streams.data(), cur_slots.data(), t0.max_level(), t0.window(), t0.window(), 0, nullptr)) != FT_OK) return rc;
-
         lap(ST_PYRAMID);
         // detections of the previous frames: cached (speculative) or computed now for the streams that need them
         std::vector<Detection> last_det(S);
@@ -148,18 +174,19 @@ public:
             starts_fresh[s] = plans[s].slot_last < 0 || trackers[s]->tracked_last(0) == 0;
             any_first |= starts_fresh[s] != 0;
         }
-        // detector on the new frames: always when speculative, otherwise only for streams that start from nothing
-        if (cells > 0 && (t0.speculative() || any_first)) {
-            std::vector<int> d_streams, d_slots, who;
-            for (int s = 0; s < S; s++)
-                if (t0.speculative() || starts_fresh[s]) { who.push_back(s); d_streams.push_back(plans[s].stream); d_slots.push_back(plans[s].slot_cur); }
-            const int cap = cells * kmax;
-            det_buf.resize((size_t)who.size() * cap); det_n.resize(who.size()); det_cells.resize((size_t)who.size() * cells);
-            if ((rc = be->fast_grid_async((int)who.size(), d_streams.data(), d_slots.data(), t0.fast_threshold(), gx, gy, kmax,
-                                          det_buf.data(), cap, det_n.data(), det_cells.data())) != FT_OK) return rc;
-            det_who = who;
-        } else {
-            det_who.clear();
+        // non-speculative: the detector runs on the new frame only for streams that start from nothing
+        DetSet& D = det[det_cur];
+        if (!t0.speculative()) {
+            D.who.clear();
+            if (cells > 0 && any_first) {
+                std::vector<int> d_streams, d_slots;
+                for (int s = 0; s < S; s++)
+                    if (starts_fresh[s]) { D.who.push_back(s); d_streams.push_back(plans[s].stream); d_slots.push_back(plans[s].slot_cur); }
+                const int cap = cells * kmax;
+                D.buf.resize((size_t)D.who.size() * cap); D.n.resize(D.who.size()); D.cells.resize((size_t)D.who.size() * cells);
+                if ((rc = be->fast_grid_async((int)D.who.size(), d_streams.data(), d_slots.data(), t0.fast_threshold(), gx, gy, kmax,
+                                              D.buf.data(), cap, D.n.data(), D.cells.data())) != FT_OK) return rc;
+            }
         }
         lap(ST_DETECT);
         jobs.clear();
@@ -173,6 +200,8 @@ public:
             const ft_lk_params prm = t0.lk_params();
             if ((rc = be->lk_track_async((int)jobs.size(), jobs.data(), &prm)) != FT_OK) return rc;
         }
+        // the wait in complete() covers this set's detector and LK, not what stage() enqueues afterwards
+        if ((rc = be->fence(&wait_token)) != FT_OK) return rc;
         lap(ST_LK_ENQUEUE);
         flush_db();   // the previous set's database writes overlap the device work queued above
         lap(ST_FINISH);
@@ -197,15 +226,16 @@ public:
         };
         int rc;
         const int cells = pend_cells, kmax = pend_kmax;
-        if ((rc = be->sync()) != FT_OK) return rc;
+        if ((rc = be->wait(wait_token)) != FT_OK) return rc;
         lap(ST_WAIT);
         std::vector<Detection>& cur_det = cur_det_buf;
         cur_det.assign(S, Detection());
         const int cap = cells * kmax;
-        for (size_t q = 0; q < det_who.size(); q++) {
-            Detection& d = cur_det[det_who[q]];
+        const DetSet& D = det[det_cur];
+        for (size_t q = 0; q < D.who.size(); q++) {
+            Detection& d = cur_det[D.who[q]];
             d.valid = true; d.per_cell = kmax; d.cells = cells;
-            d.kps = det_buf.data() + q * cap; d.n = det_n[q]; d.cell_counts = det_cells.data() + q * cells;
+            d.kps = D.buf.data() + q * cap; d.n = D.n[q]; d.cell_counts = D.cells.data() + q * cells;
         }
         pool->parallel_for(S, [&](int s) { trackers[s]->mono_finish(plans[s], cur_det[s]); });
         for (int s = 0; s < S; s++)
@@ -248,13 +278,70 @@ public:
     size_t attempted_features() const { return attempted; } // features handed to LK in the last feed
 
 private:
+    // detector output of one frame set (two sets exist: the one in flight and the staged one)
+    struct DetSet {
+        std::vector<ft_keypoint> buf;
+        std::vector<int> n, cells, who;
+    };
+
+    // ingest + pyramids + (speculative) detector of one frame set into the given ring slots
+    int enqueue_front(const double* timestamps, const FrameSource* frames, const std::vector<int>& slots, DetSet& D, bool detect,
+                      const std::function<void(int)>* lap) {
+        (void)timestamps;
+        const int S = size();
+        TrackKLT& t0 = *trackers[0];
+        int rc = FT_OK;
+        front_streams.resize(S);
+        bool all_dev = true;
+        for (int s = 0; s < S; s++) {
+            front_streams[s] = s;   // tracker s owns backend stream s (stream_base = s, camera 0)
+            all_dev &= frames[s].dev != nullptr && frames[s].cols == frames[0].cols && frames[s].rows == frames[0].rows && frames[s].step == frames[0].step;
+        }
+        if (all_dev) {   // frames already in HBM: one copy launch for the whole batch
+            dev_ptrs.resize(S);
+            for (int s = 0; s < S; s++) dev_ptrs[s] = frames[s].dev;
+            if ((rc = be->set_frames_device(S, front_streams.data(), slots.data(), dev_ptrs.data(), frames[0].cols, frames[0].rows, frames[0].step)) != FT_OK) return rc;
+        } else {
+            for (int s = 0; s < S; s++) {
+                const FrameSource& f = frames[s];
+                if (f.dev) rc = be->set_frames_device(1, &front_streams[s], &slots[s], &f.dev, f.cols, f.rows, f.step);
+                else rc = be->upload(front_streams[s], slots[s], f.host, f.cols, f.rows, f.step);
+                if (rc != FT_OK) return rc;
+            }
+        }
+        if (lap) (*lap)(ST_INGEST);
+        if ((rc = be->build_pyramid(S, front_streams.data(), slots.data(), t0.max_level(), t0.window(), t0.window(), 0, nullptr)) != FT_OK) return rc;
+        D.who.clear();
+        if (detect) {
+            const int gx = t0.grid_cols(), gy = t0.grid_rows(), kmax = t0.per_cell_max();
+            const int cells = Grider_FAST::cells_for(frames[0].cols, frames[0].rows, gx, gy);
+            if (cells > 0) {
+                const int cap = cells * kmax;
+                D.who.resize(S);
+                for (int s = 0; s < S; s++) D.who[s] = s;
+                D.buf.resize((size_t)S * cap); D.n.resize(S); D.cells.resize((size_t)S * cells);
+                if ((rc = be->fast_grid_async(S, front_streams.data(), slots.data(), t0.fast_threshold(), gx, gy, kmax, D.buf.data(), cap,
+                                              D.n.data(), D.cells.data())) != FT_OK) return rc;
+            }
+        }
+        return FT_OK;
+    }
+
     FrontendBackend* be;
     FeatureTrackerOptions options;
+    int ring = 2;
+    DetSet det[2];
+    int det_cur = 0, staged_det = 1;
+    bool staged = false;
+    std::vector<double> staged_ts;
+    std::vector<FrameSource> staged_frames;
+    std::vector<int> staged_slots, front_streams;
+    uint64_t wait_token = 0;
     std::vector<std::unique_ptr<TrackKLT>> trackers;
     std::vector<TrackKLT::MonoPlan> plans, db_plans;
     std::vector<char> starts_fresh;
     bool db_pending = false;
-    std::vector<int> streams, cur_slots, det_who;
+    std::vector<int> streams, cur_slots;
     std::vector<const void*> dev_ptrs;
     std::vector<ft_lk_job> jobs, all_jobs;
     WorkerPool* pool;
@@ -262,8 +349,8 @@ private:
     std::vector<Detection> cur_det_buf;
     bool pending = false;
     int pend_cells = 0, pend_kmax = 0;
-    std::vector<ft_keypoint> det_buf, last_buf;
-    std::vector<int> det_n, det_cells, last_n, last_cells;
+    std::vector<ft_keypoint> last_buf;
+    std::vector<int> last_n, last_cells;
     std::vector<std::vector<int>> cached_cells;
     size_t tracked = 0, attempted = 0;
     double stage_s[ST_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};

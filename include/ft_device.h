@@ -139,6 +139,13 @@ int ft_download_grad(ft_ctx* ctx, int stream, int slot, int level, int16_t* host
 
 /* Wait for everything enqueued on the context and deliver pending *_async outputs. */
 int ft_sync(ft_ctx* ctx);
+/* Partial wait.  ft_fence marks the current end of the context's queue; ft_wait(token) blocks until the queue has
+ * passed that mark and delivers the outputs of the *_async calls enqueued before it, while work enqueued after the
+ * mark (e.g. the next frame's pyramid and detector) keeps running.  At most 16 fences may be outstanding; at most
+ * two ft_fast_grid_async results and one ft_lk_track_async result may be undelivered at any time (a further call
+ * first waits for the whole queue).  No reference counterpart: the reference's OpenCV calls are synchronous. */
+int ft_fence(ft_ctx* ctx, uint64_t* token);
+int ft_wait(ft_ctx* ctx, uint64_t token);
 
 /* Timing. ft_profile(1) brackets every kernel group with HIP events on the context's queue (adds a little
  * overhead); ft_kernel_times reads and optionally resets the totals.  ft_queue_time_* time a whole region. */

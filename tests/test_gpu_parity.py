@@ -221,3 +221,35 @@ def test_error_codes(dev):
         with pytest.raises(dev.FtError) as e:            # window larger than the kernel supports
             ctx.lk_track([dict(prev=(0, 0), next=(0, 0), prev_xy=np.zeros((4, 2), np.float32))], dev.LKParams(win=41, max_level=2))
         assert e.value.code == -1
+
+
+def test_fence_wait_delivers_only_earlier_async_results(dev):
+    """ft_fence / ft_wait: outputs of async calls made before the fence are delivered by the wait, outputs of calls
+    made after it only by a later wait or sync; a stale or unknown token is refused."""
+    imgs = [synth.texture(376, 240, seed=40 + i, n_shapes=300) for i in range(3)]
+    with _ctx(dev, 376, 240, n_streams=3) as ctx:
+        for i, im in enumerate(imgs):
+            ctx.upload(i, 0, im)
+        ref = [ctx.fast_grid([i], [0], 20, 5, 5, 7) for i in range(3)]
+        out0, n0, _ = ctx.fast_grid([0], [0], 20, 5, 5, 7, sync=False)
+        tok = ctx.fence()
+        out1, n1, _ = ctx.fast_grid([1], [0], 20, 5, 5, 7, sync=False)
+        ctx.build_pyramid([2], [0], 2, 15)
+        ctx.wait(tok)
+        assert n0[0] == ref[0][1][0] and np.array_equal(out0, ref[0][0])
+        tok2 = ctx.fence()
+        ctx.wait(tok2)
+        assert n1[0] == ref[1][1][0] and np.array_equal(out1, ref[1][0])
+        # a third undelivered detector result forces a full queue wait and still delivers everything in order
+        outs = [ctx.fast_grid([i], [0], 20, 5, 5, 7, sync=False) for i in range(3)]
+        ctx.sync()
+        for i in range(3):
+            assert np.array_equal(outs[i][0], ref[i][0]) and outs[i][1][0] == ref[i][1][0]
+        with pytest.raises(dev.FtError) as e:
+            ctx.wait(12345)
+        assert e.value.code == -1
+        for _ in range(20):
+            ctx.fence()
+        with pytest.raises(dev.FtError) as e:   # the ring entry of the first token has been reused
+            ctx.wait(tok)
+        assert e.value.code == -1

@@ -76,3 +76,45 @@ def test_device_resident_frames_equal_host_upload():
         rb = b.feed_device([q.timestamps[i]], [dev[i].data_ptr()], 752, 480, 752)
         assert ra == rb
         assert np.array_equal(a.points(0)[0], b.points(0)[0])
+
+
+def _tracks(b, stream):
+    xy, ids = b.points(stream)
+    return {int(i): b.track(stream, int(i)) for i in ids}
+
+
+def test_pipelined_groups_with_lookahead_equal_plain_feed():
+    """Grouped, pipelined feeding stages the next frame set's ingest / pyramids / detector while the current set is
+    tracked (three-slot ring).  Results and feature databases must equal the plain one-set-at-a-time feed."""
+    n_streams, n_frames = 8, 14
+    seqs = [synth.Sequence(376, 240, n_frames, stream_id=20 + s) for s in range(n_streams)]
+    opts = dict(win_size=15, pyr_levels=2, num_pts=80, use_gyro_seed=1)
+
+    def run(pipelined, n_groups):
+        b = tracker.BatchTracker(n_streams, 376, 240, n_groups=n_groups, **opts)
+        for s, q in enumerate(seqs):
+            b.set_calibration(s, q.calib8, q.T_cam_imu)
+            for t, g, a in zip(q.imu_t, q.gyro, q.accel):
+                b.feed_imu(s, t, a, g)
+        tracked = attempted = 0
+        for i in range(n_frames):
+            tr, at = b.feed_host([q.timestamps[i] for q in seqs], [q.frames[i] for q in seqs], pipelined=pipelined)
+            tracked += tr
+            attempted += at
+        if pipelined:
+            tr, at = b.flush()
+            tracked += tr
+            attempted += at
+        pts = [b.points(s) for s in range(n_streams)]
+        dbs = [(b.database_size(s), _tracks(b, s)) for s in range(n_streams)]
+        return tracked, attempted, pts, dbs
+
+    plain = run(False, 1)
+    piped = run(True, 2)
+    assert plain[0] == piped[0] and plain[1] == piped[1] and plain[0] > 0
+    for (xy_a, id_a), (xy_b, id_b) in zip(plain[2], piped[2]):
+        assert np.array_equal(id_a, id_b) and np.array_equal(xy_a, xy_b)
+    for (n_a, tr_a), (n_b, tr_b) in zip(plain[3], piped[3]):
+        assert n_a == n_b and tr_a.keys() == tr_b.keys()
+        for k in tr_a:
+            assert np.array_equal(tr_a[k][0], tr_b[k][0]) and np.array_equal(tr_a[k][1], tr_b[k][1])
