@@ -9,11 +9,14 @@
 //  * Template: each lane samples its SEGLEN pixels of I (x32) and evaluates the Scharr gradients of its samples from
 //    the staged I region (same arithmetic as the gradient image kernel, so no gradient image has to be read: a
 //    window touches a few bytes of every 128-byte line it crosses, and the 4-byte-per-pixel gradient lines were the
-//    largest part of this kernel's memory traffic).  Samples stay in registers for the whole level.
+//    largest part of this kernel's memory traffic).  The kernel is bound by vector-instruction issue, so all of
+//    this runs on packed 16-bit pairs: v_pk_* for the Scharr taps (|values| <= 4080), v_dot2_i32_i16 for every
+//    bilinear blend and for the normal-equation sums.  Samples stay in registers for the whole level.
 //  * Target: every Newton iteration reads two LDS rows per lane, so the dependent chain position -> pixels ->
 //    (b1,b2) -> position never waits on memory.  A window that walks out of the staged region re-stages it.
-//  * Sums are exact integers: lanes accumulate in int32, the wave reduction runs on 16-bit halves with DPP adds
-//    (no LDS traffic), and the total is rounded to float once, so results do not depend on the reduction order.
+//  * Sums are exact integers: lanes accumulate in int32, the wave reduction runs on bit fields narrow enough not
+//    to overflow, with DPP adds (no LDS traffic), and the total is rounded to float once, so results do not depend
+//    on the reduction order.
 #pragma once
 #include "ft_common.hpp"
 
@@ -50,10 +53,13 @@ struct LKArgs {
 
 constexpr int LK_MARGIN = 5;                                     // staged margin around the target window, pixels
 constexpr int LK_RW_DWORDS = (32 + 1 + 2 * LK_MARGIN + 3 + 3) / 4;   // widest staged row: 12 dwords
-constexpr int LK_RH_MAX = 32 + 1 + 2 * LK_MARGIN;                // tallest staged region: 43 rows
+
+typedef short lk_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lk_v2s v2s(uint32_t x) { return __builtin_bit_cast(lk_v2s, x); }
+__device__ __forceinline__ uint32_t u32(lk_v2s x) { return __builtin_bit_cast(uint32_t, x); }
 
 // ---- wave-wide exact integer sum (result uniform in all lanes) ----
-__device__ inline int wave_sum_i32(int v) {
+__device__ __forceinline__ int wave_sum_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
@@ -63,18 +69,22 @@ __device__ inline int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// sum of one int32 per lane whose total may exceed 32 bits: reduce the two 16-bit halves separately
-__device__ inline double wave_sum_exact(int v) {
-    const int lo = v & 0xffff, hi = v >> 16;
-    const int slo = wave_sum_i32(lo), shi = wave_sum_i32(hi);
-    return (double)shi * 65536.0 + (double)slo;
+// sums over the wave of two int32 values per lane with |v| < 2^30, exactly, as floats rounded once.  The low 10
+// bits of both travel in one register (two 16-bit fields: 64 * 1023 < 2^16), the high parts in one register each.
+__device__ __forceinline__ void wave_sum_exact2(int v1, int v2, float& s1, float& s2) {
+    const int lo = (v1 & 1023) | ((v2 & 1023) << 16);
+    const int slo = wave_sum_i32(lo), sh1 = wave_sum_i32(v1 >> 10), sh2 = wave_sum_i32(v2 >> 10);
+    s1 = (float)((double)sh1 * 1024.0 + (double)(slo & 0xffff));
+    s2 = (float)((double)sh2 * 1024.0 + (double)((uint32_t)slo >> 16));
 }
-
-__device__ inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+__device__ __forceinline__ float wave_sum_exact1(int v) {
+    const int slo = wave_sum_i32(v & 1023), sh = wave_sum_i32(v >> 10);
+    return (float)((double)sh * 1024.0 + (double)slo);
+}
 
 struct BilinW { int w00, w01, w10, w11; };
 
-__device__ inline BilinW bilin_weights(float a, float b) {
+__device__ __forceinline__ BilinW bilin_weights(float a, float b) {
     BilinW r;
     r.w00 = (int)__builtin_rintf((1.f - a) * (1.f - b) * 16384.f);
     r.w01 = (int)__builtin_rintf(a * (1.f - b) * 16384.f);
@@ -83,9 +93,14 @@ __device__ inline BilinW bilin_weights(float a, float b) {
     return r;
 }
 
-typedef short lk_v2s __attribute__((ext_vector_type(2)));
-__device__ inline int dot2_acc(uint32_t pair, uint32_t wpair, int acc) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, pair), __builtin_bit_cast(lk_v2s, wpair), acc, false);
+__device__ __forceinline__ int dot2_acc(uint32_t pair, uint32_t wpair, int acc) {
+    return __builtin_amdgcn_sdot2(v2s(pair), v2s(wpair), acc, false);
+}
+// upper 16-bit field of lo followed by the lower field of hi: the pair one element further along
+__device__ __forceinline__ uint32_t next_pair(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
+// low halves of two ints as one 16-bit pair
+__device__ __forceinline__ uint32_t pack_lo16(int second, int first) {
+    return __builtin_amdgcn_perm((uint32_t)second, (uint32_t)first, 0x05040100u);
 }
 
 // ---- image regions in LDS ----
@@ -95,20 +110,20 @@ struct Region {
 };
 
 // single-reflection REFLECT_101: exact for -len < p < 2*len - 1
-__device__ inline int reflect101_once(int p, int len) {
+__device__ __forceinline__ int reflect101_once(int p, int len) {
     p = p < 0 ? -p : p;
     return p >= len ? 2 * len - 2 - p : p;
 }
 
-constexpr int LK_REACH = FT_MAX_WIN + 1 + LK_MARGIN + 4;   // farthest a staged region extends beyond a window origin
+struct __attribute__((packed)) LkU32Unaligned { uint32_t v; };
 
 // load image columns [x_first, x_last] x rows [y_first, y_first + n_rows) into LDS (REFLECT_101 outside the image).
-// Lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...  On levels larger than the reach
-// of a region (all but degenerate ones) a lane issues all its loads before the first one is consumed, so a region
-// costs one memory round trip.  The caller orders the LDS writes before its reads with lds_fence().
+// Lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...; the LDS array holds 4*MAXR rows.
+// A lane issues all its loads before the first one is consumed, so a region costs one memory round trip.  The
+// caller orders the LDS writes before its reads with lds_fence().
 template <int MAXR>
 __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
-                                               int x_first, int x_last, int y_first, int n_rows, int lane) {
+                                               int x_first, int x_last, int y_first, int n_rows, int lane, int a_reach_w, int a_reach_h) {
     Region R;
     R.rx0 = (x_first >> 2) << 2;
     R.ry0 = y_first;
@@ -116,23 +131,55 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
     R.rh = n_rows;                         // <= 4 * MAXR
     const int c = lane & 15, rr = lane >> 4;
     const int gx = R.rx0 + 4 * c;
-    const bool col_used = c < R.rwd;
-    const bool col_in = gx >= 0 && gx + 3 < w;
-    const bool roomy = w > 2 * LK_REACH && h > 2 * LK_REACH;   // wave-uniform
-    if (roomy && (col_in || !col_used)) {
-        const uint32_t xoff = col_used ? (uint32_t)gx : 0u;     // unused lanes load something harmless
-        uint32_t v[MAXR];
+    // wave-uniform cases, cheapest first
+    const bool interior = R.rx0 >= 0 && R.rx0 + 4 * LK_RW_DWORDS <= w && R.ry0 >= 0 && R.ry0 + R.rh <= h;
+    if (interior) {
+        // every staged byte is an image byte: no border arithmetic.  Rows past the region (never read) are clamped
+        // into the image so that all 4*MAXR rows can be loaded and stored without per-row predicates.
+        if (c < LK_RW_DWORDS) {
+            uint32_t v[MAXR];
 #pragma unroll
-        for (int k = 0; k < MAXR; k++) {
-            const int sy = reflect101_once(R.ry0 + min(rr + 4 * k, R.rh - 1), h);
-            v[k] = *reinterpret_cast<const uint32_t*>(img + ((uint32_t)sy * pitch + xoff));   // uniform base + 32-bit offset
-        }
-        if (col_used) {
+            for (int k = 0; k < MAXR; k++) {
+                const int sy = min(R.ry0 + rr + 4 * k, h - 1);
+                v[k] = *reinterpret_cast<const uint32_t*>(img + (__umul24(sy, pitch) + (uint32_t)gx));   // uniform base + 32-bit offset
+            }
+            uint32_t* dst = lds + rr * LK_RW_DWORDS + c;
 #pragma unroll
-            for (int k = 0; k < MAXR; k++)
-                if (rr + 4 * k < R.rh) lds[(rr + 4 * k) * LK_RW_DWORDS + c] = v[k];
+            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_RW_DWORDS] = v[k];
         }
-    } else if (col_used) {   // dword straddles the image border, or a degenerate level: byte by byte, general reflection
+        return R;
+    }
+    // The region reaches at most a window plus its margins beyond the image.  On a level larger than that, one
+    // reflection per axis is exact, and a dword is assembled from two loads with a byte permute: A = the dword
+    // itself (its bytes inside the image), B = the dword that holds the mirrored bytes (REFLECT_101 reverses their
+    // order).  rx0 is a multiple of 4, so a dword never straddles the left border, only the right one.
+    const bool single_reflection = w >= a_reach_w && h >= a_reach_h;
+    if (single_reflection) {
+        if (c < LK_RW_DWORDS) {
+            const int gxc = min(gx, R.rx0 + 4 * (R.rwd - 1));    // columns past the region are never read
+            const int n_in = w - gxc;                            // bytes of the dword left of the right border
+            uint32_t offA, offB, sel;
+            if (gxc < 0) { offB = (uint32_t)(-gxc - 3); offA = offB; sel = 0x04050607u; }
+            else if (n_in >= 4) { offA = (uint32_t)gxc; offB = offA; sel = 0x03020100u; }
+            else {
+                offB = (uint32_t)(2 * w - 5 - gxc);
+                offA = n_in > 0 ? (uint32_t)gxc : offB;
+                sel = n_in <= 0 ? 0x04050607u : (n_in == 1 ? 0x04050600u : (n_in == 2 ? 0x04050100u : 0x04020100u));
+            }
+            uint32_t va[MAXR], vb[MAXR];
+#pragma unroll
+            for (int k = 0; k < MAXR; k++) {
+                const uint32_t ro = __umul24(reflect101_once(R.ry0 + min(rr + 4 * k, R.rh - 1), h), pitch);
+                va[k] = reinterpret_cast<const LkU32Unaligned*>(img + (ro + offA))->v;
+                vb[k] = reinterpret_cast<const LkU32Unaligned*>(img + (ro + offB))->v;
+            }
+            uint32_t* dst = lds + rr * LK_RW_DWORDS + c;
+#pragma unroll
+            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_RW_DWORDS] = __builtin_amdgcn_perm(vb[k], va[k], sel);
+        }
+        return R;
+    }
+    if (c < R.rwd) {   // degenerate level (smaller than a window's reach): byte by byte, general reflection
 #pragma unroll 1
         for (int row = rr; row < R.rh; row += 4) {
             const uint8_t* src = img + (size_t)reflect101(R.ry0 + row, h) * pitch;
@@ -146,44 +193,42 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
 }
 
 // one wave per workgroup: LDS operations of a wave complete in order, this only pins the compiler's ordering
-__device__ inline void lds_fence() {
+__device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ inline bool region_holds(const Region& R, int inx, int iny, int ext_w, int win_h) {
+__device__ __forceinline__ bool region_holds(const Region& R, int inx, int iny, int ext_w, int win_h) {
     return inx >= R.rx0 && inx + ext_w + 1 <= R.rx0 + 4 * R.rwd && iny >= R.ry0 && iny + win_h + 1 <= R.ry0 + R.rh;
 }
 
-// N consecutive bytes of one staged row starting at byte offset byte_off, as ints
-template <int N>
-__device__ inline void read_row_bytes(const uint32_t* __restrict__ lds, int row, int byte_off, int (&out)[N]) {
-    constexpr int NDW = (N + 3 + 3) / 4;
+// 2*NP consecutive bytes of one staged row starting at byte offset byte_off, as NP pairs of 16-bit values:
+// P[m] = (byte 2m, byte 2m+1)
+template <int NP>
+__device__ __forceinline__ void read_row_pairs_even(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&P)[NP]) {
+    constexpr int NE = (2 * NP + 3) / 4;
     const uint32_t* p = lds + row * LK_RW_DWORDS + (byte_off >> 2);
     const uint32_t sh = byte_off & 3;
-    uint32_t d[NDW + 1];
+    uint32_t d[NE + 1];
 #pragma unroll
-    for (int q = 0; q < NDW; q++) d[q] = p[q];
-    d[NDW] = 0;
+    for (int q = 0; q <= NE; q++) d[q] = p[q];
 #pragma unroll
-    for (int q = 0; q < (N + 3) / 4; q++) {
+    for (int q = 0; q < NE; q++) {
         const uint32_t e = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-            if (4 * q + b < N) out[4 * q + b] = (e >> (8 * b)) & 0xff;
+        P[2 * q] = __builtin_amdgcn_perm(0u, e, 0x0c010c00u);
+        if (2 * q + 1 < NP) P[2 * q + 1] = __builtin_amdgcn_perm(0u, e, 0x0c030c02u);
     }
 }
 
 // (J[k], J[k+1]) pairs, k = 0..SEGLEN-1, of one staged row as packed 16-bit pairs for v_dot2
 template <int SEGLEN>
-__device__ inline void read_row_pairs(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&pairs)[SEGLEN]) {
+__device__ __forceinline__ void read_row_pairs(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&pairs)[SEGLEN]) {
     constexpr int NDW = SEGLEN / 4 + 1;
     const uint32_t* p = lds + row * LK_RW_DWORDS + (byte_off >> 2);
     const uint32_t sh = byte_off & 3;
     uint32_t d[NDW + 1];
 #pragma unroll
-    for (int q = 0; q < NDW; q++) d[q] = p[q];
-    d[NDW] = 0;
+    for (int q = 0; q <= NDW; q++) d[q] = p[q];
     uint32_t e[NDW];   // bytes realigned to the window column
 #pragma unroll
     for (int q = 0; q < NDW; q++) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
@@ -196,14 +241,53 @@ __device__ inline void read_row_pairs(const uint32_t* __restrict__ lds, int row,
     }
 }
 
+// One row of Scharr gradients on packed pairs, blended into the per-sample sums.  U, M, L: pixel pairs of the rows
+// above, at and below the gradient row; column index c of a pair array is image column ipx + x0 - 1 + c.
+// EDGE: zero the gradients that lie outside the image (the derivative image is zero-padded).
+template <int SEGLEN, bool EDGE>
+__device__ __forceinline__ void scharr_row_blend(const uint32_t (&U)[SEGLEN / 2 + 2], const uint32_t (&M)[SEGLEN / 2 + 2],
+                                                 const uint32_t (&L)[SEGLEN / 2 + 2], uint32_t wpair, int (&sX)[SEGLEN], int (&sY)[SEGLEN],
+                                                 bool row_in, int col0, int w) {
+    constexpr int NP = SEGLEN / 2 + 2;
+    lk_v2s T0[NP], T1[NP];
+#pragma unroll
+    for (int m = 0; m < NP; m++) {
+        T0[m] = (v2s(U[m]) + v2s(L[m])) * (short)3 + v2s(M[m]) * (short)10;   // <= 4080
+        T1[m] = v2s(L[m]) - v2s(U[m]);
+    }
+    // pairs starting at odd columns c = 2m+1: (G[2m+1], G[2m+2])
+    uint32_t PX[NP - 1], PY[NP - 1];
+#pragma unroll
+    for (int m = 0; m < NP - 1; m++) {
+        PX[m] = u32(T0[m + 1] - T0[m]);
+        const lk_v2s mid = v2s(next_pair(u32(T1[m + 1]), u32(T1[m])));
+        PY[m] = u32((T1[m] + T1[m + 1]) * (short)3 + mid * (short)10);
+    }
+#pragma unroll
+    for (int k = 0; k < SEGLEN; k++) {
+        // sample k blends gradient columns c = k+1 and k+2
+        uint32_t px, py;
+        if ((k & 1) == 0) { px = PX[k / 2]; py = PY[k / 2]; }
+        else { px = next_pair(PX[(k + 1) / 2], PX[(k - 1) / 2]); py = next_pair(PY[(k + 1) / 2], PY[(k - 1) / 2]); }
+        if (EDGE) {
+            const int gx = col0 + k + 1;
+            const uint32_t keep = ((row_in && gx >= 0 && gx < w) ? 0xffffu : 0u) | ((row_in && gx + 1 >= 0 && gx + 1 < w) ? 0xffff0000u : 0u);
+            px &= keep; py &= keep;
+        }
+        sX[k] = dot2_acc(px, wpair, sX[k]);
+        sY[k] = dot2_acc(py, wpair, sY[k]);
+    }
+}
+
 // SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more staged rows per lane)
 template <int SEGLEN, bool TALL>
 __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
-    __shared__ uint32_t jlds[LK_RH_MAX * LK_RW_DWORDS + 4];         // target region (+ slack: row reads are dword-granular)
-    __shared__ uint32_t ilds[(32 + 3) * LK_RW_DWORDS + 4];          // template region: window + Scharr apron
+    constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
+    __shared__ uint32_t jlds[4 * J_ROWS * LK_RW_DWORDS + 4];        // target region (+ slack: row reads are dword-granular)
+    __shared__ uint32_t ilds[4 * I_ROWS * LK_RW_DWORDS + 4];        // template region: window + Scharr apron
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     const int lane = threadIdx.x;
@@ -215,8 +299,15 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     const int rc = row_ok ? r : wh - 1;          // lanes below the window reuse its last row (results masked)
     const int ext_w = a.segs * SEGLEN;           // columns the lanes touch: [0, ext_w]
     const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
+    // smallest level size for which a staged region needs at most one reflection per axis (with some slack)
+    const int reach_w = ext_w + 2 * LK_MARGIN + 8, reach_h = wh + 2 * LK_MARGIN + 8;
+    // which of the lane's samples belong to the window: 16-bit masks for the packed (sample 2m, sample 2m+1) pairs
+    const int n_valid = row_ok ? min(max(ww - x0, 0), SEGLEN) : 0;
+    uint32_t keep[SEGLEN / 2];
+#pragma unroll
+    for (int m = 0; m < SEGLEN / 2; m++) keep[m] = (n_valid > 2 * m ? 0xffffu : 0u) | (n_valid > 2 * m + 1 ? 0xffff0000u : 0u);
 
-    // forward: template = prev pyramid at prev_xy, target = next pyramid, guess from next_xy / H / prev
+    // forward: template = prev pyramid at prev_xy, target = next pyramid, guess from guess_xy / H / prev
     // backward: template = next pyramid at the forward result, target = prev pyramid, guess = original point
     const int img_I = a.backward ? job->img_next : job->img_prev;
     const int img_J = a.backward ? job->img_prev : job->img_next;
@@ -249,7 +340,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     for (int level = a.max_level; level >= 0; level--) {
         int w = job->w0, h = job->h0;
         for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
-        const float scale = (float)(1. / (1 << level));
+        const float scale = __builtin_bit_cast(float, (uint32_t)(127 - level) << 23);   // 2^-level
         float px = tx * scale, py = ty * scale;
         float nx, ny;
         if (level == a.max_level) {
@@ -276,69 +367,62 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         const uint8_t* imgJ = level_img(a.A, img_J, level);
         nx -= half_x; ny -= half_y;
         const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-        const Region RI = stage_region<I_ROWS>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane);
+        const Region RI = stage_region<I_ROWS>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
         Region R;
         R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
         if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h))
-            R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane);
+            R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
         lds_fence();
 
         // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
-        int Iw[SEGLEN];
-        int Gx[SEGLEN], Gy[SEGLEN];
+        // Kept for the iterations: Cw[k] = 256 - 512 * I(k) (folds the subtraction of the template sample into the
+        // accumulator of the target blend), and the gradients as pairs GX[m] = (Ix(2m), Ix(2m+1)), GY[m] likewise.
+        int Cw[SEGLEN];
+        uint32_t GX[SEGLEN / 2], GY[SEGLEN / 2];
         float A11, A12, A22;
         {
             const BilinW bw = bilin_weights(px - ipx, py - ipy);
-            // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2.
-            // Rows are consumed one at a time (rolling three-row window) and folded into the weighted sums at once.
-            const int boff = ipx + x0 - 1 - RI.rx0;             // columns ipx+x0-1 .. ipx+x0+SEGLEN+1
-            int ra[SEGLEN + 3], rb[SEGLEN + 3], rcw[SEGLEN + 3];
-            read_row_bytes<SEGLEN + 3>(ilds, rc, boff, ra);
-            read_row_bytes<SEGLEN + 3>(ilds, rc + 1, boff, rb);
-            int sI[SEGLEN], sX[SEGLEN], sY[SEGLEN];
+            const uint32_t wtop = (uint32_t)bw.w00 | ((uint32_t)bw.w01 << 16), wbot = (uint32_t)bw.w10 | ((uint32_t)bw.w11 << 16);
+            // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
+            // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
+            const int boff = ipx + x0 - 1 - RI.rx0;
+            uint32_t Ra[NP], Rb[NP], Rc[NP], Rd[NP];
+            read_row_pairs_even<NP>(ilds, rc, boff, Ra);
+            read_row_pairs_even<NP>(ilds, rc + 1, boff, Rb);
+            read_row_pairs_even<NP>(ilds, rc + 2, boff, Rc);
+            read_row_pairs_even<NP>(ilds, rc + 3, boff, Rd);
+            int sX[SEGLEN], sY[SEGLEN];
 #pragma unroll
-            for (int k = 0; k < SEGLEN; k++) { sI[k] = rb[k + 1] * bw.w00 + rb[k + 2] * bw.w01; sX[k] = 0; sY[k] = 0; }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                read_row_bytes<SEGLEN + 3>(ilds, rc + 2 + j, boff, rcw);
-                const int wl = j == 0 ? bw.w00 : bw.w10, wr = j == 0 ? bw.w01 : bw.w11;
-                const int gy = ipy + rc + j;
-                const bool row_in = gy >= 0 && gy < h;
-                if (j == 1) {
-#pragma unroll
-                    for (int k = 0; k < SEGLEN; k++) sI[k] += rb[k + 1] * bw.w10 + rb[k + 2] * bw.w11;
-                }
-                int t0p = 0, t1p = 0, t0c = 0, t1c = 0;   // vertical sums of the two previous columns
-#pragma unroll
-                for (int c = 0; c < SEGLEN + 3; c++) {
-                    const int t0 = (ra[c] + rcw[c]) * 3 + rb[c] * 10;
-                    const int t1 = rcw[c] - ra[c];
-                    if (c >= 2) {
-                        const int k = c - 2;                    // sample column ipx + x0 + k
-                        const int gxp = ipx + x0 + k;
-                        const bool in = row_in && gxp >= 0 && gxp < w;
-                        const int ix = in ? t0 - t0p : 0;                       // zero outside the image
-                        const int iy = in ? (t1 + t1p) * 3 + t1c * 10 : 0;
-                        if (k < SEGLEN) { sX[k] += ix * wl; sY[k] += iy * wl; }
-                        if (k > 0) { sX[k - 1] += ix * wr; sY[k - 1] += iy * wr; }
-                    }
-                    t0p = t0c; t1p = t1c; t0c = t0; t1c = t1;
-                }
-#pragma unroll
-                for (int c = 0; c < SEGLEN + 3; c++) { ra[c] = rb[c]; rb[c] = rcw[c]; }
+            for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
+            const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
+            if (inside) {
+                scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
+                scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
+            } else {
+                const int gy = ipy + rc;
+                scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, ipx + x0 - 1, w);
+                scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, ipx + x0 - 1, w);
             }
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
-            for (int k = 0; k < SEGLEN; k++) {
-                const bool ok = row_ok && (x0 + k < ww);
-                const int ix = ok ? descale(sX[k], 14) : 0;
-                const int iy = ok ? descale(sY[k], 14) : 0;
-                Iw[k] = descale(sI[k], 9); Gx[k] = ix; Gy[k] = iy;
-                a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+            for (int m = 0; m < SEGLEN / 2; m++) {
+                GX[m] = pack_lo16(sX[2 * m + 1] >> 14, sX[2 * m] >> 14) & keep[m];
+                GY[m] = pack_lo16(sY[2 * m + 1] >> 14, sY[2 * m] >> 14) & keep[m];
+                a11 = dot2_acc(GX[m], GX[m], a11);
+                a12 = dot2_acc(GX[m], GY[m], a12);
+                a22 = dot2_acc(GY[m], GY[m], a22);
             }
-            A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
-            A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
-            A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+#pragma unroll
+            for (int k = 0; k < SEGLEN; k++) {
+                // sample k blends pixel columns c = k+1, k+2 of region rows rc+1, rc+2
+                const uint32_t pb = (k & 1) ? Rb[(k + 1) / 2] : next_pair(Rb[k / 2 + 1], Rb[k / 2]);
+                const uint32_t pc = (k & 1) ? Rc[(k + 1) / 2] : next_pair(Rc[k / 2 + 1], Rc[k / 2]);
+                const int iw = dot2_acc(pc, wbot, dot2_acc(pb, wtop, 256)) >> 9;
+                Cw[k] = 256 - (iw << 9);
+            }
+            wave_sum_exact2(a11, a22, A11, A22);
+            A12 = wave_sum_exact1(a12);
+            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
@@ -361,7 +445,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             }
             n_iter = j + 1;
             if (!region_holds(R, inx, iny, ext_w, wh)) {
-                R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane);
+                R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
                 lds_fence();
             }
             const BilinW jw = bilin_weights(nx - inx, ny - iny);
@@ -372,19 +456,23 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             read_row_pairs<SEGLEN>(jlds, row + 1, boff, p1);
             int b1 = 0, b2 = 0;
 #pragma unroll
-            for (int k = 0; k < SEGLEN; k++) {
-                const int diff = (dot2_acc(p1[k], wbot, dot2_acc(p0[k], wtop, 256)) >> 9) - Iw[k];
-                b1 += diff * Gx[k];
-                b2 += diff * Gy[k];
+            for (int m = 0; m < SEGLEN / 2; m++) {
+                const int d0 = dot2_acc(p1[2 * m], wbot, dot2_acc(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
+                const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_acc(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
+                const uint32_t dp = pack_lo16(d1, d0);
+                b1 = dot2_acc(dp, GX[m], b1);
+                b2 = dot2_acc(dp, GY[m], b2);
             }
-            const float fb1 = (float)wave_sum_exact(b1) * FLT_SCALE;
-            const float fb2 = (float)wave_sum_exact(b2) * FLT_SCALE;
+            float fb1, fb2;
+            wave_sum_exact2(b1, b2, fb1, fb2);
+            fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nx += dx; ny += dy;
             outx = nx + half_x; outy = ny + half_y;
             if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            // |dx + pdx| < 0.01 and |dy + pdy| < 0.01 in double precision: for a float, "< 0.01" is "< the float above 0.01"
+            if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
                 break;
             }
@@ -400,7 +488,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 st = 0;
             } else {
                 if (!region_holds(R, iqx, iqy, ext_w, wh)) {
-                    R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane);
+                    R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
                     lds_fence();
                 }
                 const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
@@ -412,8 +500,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 int e = 0;
 #pragma unroll
                 for (int k = 0; k < SEGLEN; k++) {
-                    const int diff = (dot2_acc(p1[k], wbot, dot2_acc(p0[k], wtop, 256)) >> 9) - Iw[k];
-                    if (row_ok && (x0 + k < ww)) e += abs(diff);
+                    const int diff = dot2_acc(p1[k], wbot, dot2_acc(p0[k], wtop, Cw[k])) >> 9;
+                    if (k < n_valid) e += abs(diff);
                 }
                 const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
                 errv = errsum * 1.f / (float)(32 * ww * wh);
