@@ -52,13 +52,16 @@ def level_sizes(w, h, max_level):
     return out
 
 
-def pyramid_kernel_bytes(w, h, max_level, with_gradients):
+def pyramid_kernel_bytes(w, h, max_level, with_gradients, with_ingest):
     """Algorithmic bytes of the pyramid build of one frame: read every level that has a successor, write every
-    level above 0; with gradient images additionally read every level and write 4 B/px of (Ix, Iy)."""
+    level above 0; with gradient images additionally read every level and write 4 B/px of (Ix, Iy); with ingest
+    (frame -> level 0 in the same pass) additionally write level 0."""
     s = [a * b for a, b in level_sizes(w, h, max_level)]
     by = sum(s[:-1]) + sum(s[1:])
     if with_gradients:
         by += sum(s) + 4 * sum(s)
+    if with_ingest:
+        by += s[0]
     return by
 
 
@@ -216,14 +219,14 @@ def main():
 
     if rank == 0:
         # algorithmic bytes per launch group (= one step of all streams of this GPU)
-        pyr_bytes = pyramid_kernel_bytes(w, h, wl["opts"]["pyr_levels"], with_gradients=False) * S
+        pyr_bytes = pyramid_kernel_bytes(w, h, wl["opts"]["pyr_levels"], with_gradients=False, with_ingest=not args.host_frames) * S
         lk_bytes = lk_kernel_bytes(wl["opts"]["win_size"], kt.lk_level_visits, kt.lk_iterations) / max(1, kt.lk_launches)
         kinds = {
             "pyramid": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
             "lk_track": (kt.lk_ms, kt.lk_launches, lk_bytes),
             "fast_grid": (kt.fast_ms, kt.fast_launches, w * h * S),
         }
-        kernel_names = {"pyramid": "level_kernel (pyrDown, one launch per level, all streams of one step)",
+        kernel_names = {"pyramid": "level_kernel (frame ingest + pyrDown, one launch per level, all streams of one step)",
                         "lk_track": "lk_kernel (template + Newton iterations, all levels, all features of one step)",
                         "fast_grid": "fast_detect_kernel + fast_topk_kernel (all streams of one step)"}
         per_kernel = {}

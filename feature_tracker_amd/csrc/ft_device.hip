@@ -60,6 +60,9 @@ struct PendingFast {
 struct ft_ctx {
     int device = 0;
     ft_limits lim{};
+    // One in-order queue for everything.  (A second, higher-priority queue for the tracking batches was tried: a
+    // high-priority queue that waits for an event of a normal-priority queue can starve that queue and hang the
+    // device, and with equal priorities there was no gain.)
     hipStream_t q = nullptr;
     ArenaDesc arena{};
     int lvl_w[FT_MAX_LEVELS]{}, lvl_h[FT_MAX_LEVELS]{};   // geometry of the largest frame
@@ -245,20 +248,23 @@ static int collect_images(ft_ctx* c, int n, const int* streams, const int* slots
     return FT_OK;
 }
 
-static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool down, bool grad) {
+// levels from_level..top of the images in L: pyrDown (level l -> l+1 for l < top) and/or gradients of every level
+static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool down, bool grad, int from_level = 0, bool timed = true) {
     EventPair ep;
-    prof_begin(c, 0, ep);
+    if (timed) prof_begin(c, 0, ep);
     int lw = w, lh = h;
+    const FramePtrs none{};
     for (int l = 0; l <= top; l++) {
         const int do_down = (down && l < top) ? 1 : 0;
         const int do_grad = grad ? 1 : 0;
-        if (do_down || do_grad) {
+        if (l >= from_level && (do_down || do_grad)) {
             const int tiles = ((lw + LV_TX - 1) / LV_TX) * ((lh + LV_TY - 1) / LV_TY);
-            hipLaunchKernelGGL(level_kernel, dim3(xcd_grid(tiles * L.n)), dim3(256), 0, c->q, c->arena, L, l, lw, lh, do_grad, do_down);
+            hipLaunchKernelGGL((level_kernel<false>), dim3(xcd_grid(tiles * L.n)), dim3(256), 0, c->q, c->arena, L, none, 0, l, lw, lh,
+                               (uint64_t)0, do_grad, do_down);
         }
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
     }
-    prof_end(c, ep);
+    if (timed) prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
     return FT_OK;
 }
@@ -470,6 +476,44 @@ int ft_build_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, int
         SlotState& S = c->slots[L.idx[i]];
         S.levels = top + 1;
         S.grad_levels = with_gradients ? top + 1 : 0;
+        if (achieved) achieved[i] = top;
+    }
+    return FT_OK;
+}
+
+int ft_set_frames_device_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride,
+                                 int max_level, int win_w, int win_h, int* achieved) {
+    if (!c || n < 1 || n > FT_MAX_BATCH || !streams || !slots || !dev || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
+    if (max_level < 0 || win_w < 3 || win_h < 3) return FT_E_INVALID;
+    if (w > c->lim.max_width || h > c->lim.max_height || max_level + 1 > c->lim.max_levels) return FT_E_LIMIT;
+    ImgList L;
+    L.n = n;
+    for (int i = 0; i < n; i++) {
+        const int si = slot_index(c, streams[i], slots[i]);
+        if (si < 0 || !dev[i]) return FT_E_INVALID;
+        L.idx[i] = si;
+    }
+    FT_HIP(c, hipSetDevice(c->device));
+    const int top = achieved_level(w, h, win_w, win_h, max_level);
+    // level 0 and level 1 come out of one pass over the caller's frames
+    EventPair ep;
+    prof_begin(c, 0, ep);
+    const int tiles = ((w + LV_TX - 1) / LV_TX) * ((h + LV_TY - 1) / LV_TY);
+    for (int first = 0; first < n; first += FRAME_PTRS) {
+        const int m = std::min(FRAME_PTRS, n - first);
+        FramePtrs F{};
+        for (int i = 0; i < m; i++) F.p[i] = static_cast<const uint8_t*>(dev[first + i]);
+        hipLaunchKernelGGL((level_kernel<true>), dim3(xcd_grid(tiles * m)), dim3(256), 0, c->q, c->arena, L, F, first, 0, w, h,
+                           (uint64_t)stride, 0, top > 0 ? 1 : 0);
+    }
+    FT_HIP(c, hipGetLastError());
+    if (top > 1) {
+        const int rc = run_levels(c, L, w, h, top, true, false, 1, false);
+        if (rc) return rc;
+    }
+    prof_end(c, ep);   // one timed group: ingest + every level
+    for (int i = 0; i < n; i++) {
+        c->slots[L.idx[i]] = SlotState{w, h, top + 1, 0};
         if (achieved) achieved[i] = top;
     }
     return FT_OK;

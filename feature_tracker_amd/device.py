@@ -52,7 +52,8 @@ class ft_kernel_time(C.Structure):
 
 
 # every symbol include/ft_device.h declares
-SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device", "ft_build_pyramid",
+SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device",
+           "ft_set_frames_device_pyramid", "ft_build_pyramid",
            "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_fast_grid", "ft_fast_grid_async",
            "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
@@ -94,6 +95,7 @@ def load_library():
     lib.ft_upload.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t]
     lib.ft_set_frame_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t]
     lib.ft_set_frames_device.argtypes = [vp, C.c_int, ip, ip, C.POINTER(vp), C.c_int, C.c_int, C.c_size_t]
+    lib.ft_set_frames_device_pyramid.argtypes = [vp, C.c_int, ip, ip, C.POINTER(vp), C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, ip]
     lib.ft_build_pyramid.argtypes = [vp, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip]
     lib.ft_build_gradients.argtypes = [vp, C.c_int, ip, ip]
     lib.ft_lk_track.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
@@ -200,6 +202,17 @@ class DeviceContext:
         l, lp = _ints(slots)
         ptrs = (C.c_void_p * len(s))(*[int(p) for p in dev_ptrs])
         self._check(self.lib.ft_set_frames_device(self._ctx, len(s), sp, lp, ptrs, w, h, stride), "ft_set_frames_device")
+
+    def set_frames_device_pyramid(self, streams, slots, dev_ptrs, w, h, stride, max_level=3, win=15):
+        """Ingest device-resident frames and build their pyramids (no gradient images) in one pass."""
+        s, sp = _ints(streams)
+        l, lp = _ints(slots)
+        win_w, win_h = (win, win) if np.isscalar(win) else win
+        ptrs = (C.c_void_p * len(s))(*[int(p) for p in dev_ptrs])
+        ach = np.zeros(len(s), dtype=np.int32)
+        self._check(self.lib.ft_set_frames_device_pyramid(self._ctx, len(s), sp, lp, ptrs, w, h, stride, max_level, win_w, win_h,
+                                                          ach.ctypes.data_as(C.POINTER(C.c_int))), "ft_set_frames_device_pyramid")
+        return ach
 
     def build_pyramid(self, streams, slots, max_level=3, win=15, with_gradients=True):
         s, sp = _ints(streams)

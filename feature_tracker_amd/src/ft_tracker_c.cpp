@@ -80,8 +80,9 @@ struct ftk_tracker {
 };
 
 // One stream group = one device context + one TrackKLTBatch + one host driver thread.  Groups share nothing, so
-// their host bookkeeping and their device queues run concurrently; frames are posted to a two-deep mailbox per
-// group so that a group can start on frame k+1 while the caller still collects frame k.
+// their host bookkeeping and their device queues run concurrently; frames are posted to a mailbox ring per group
+// (MAIL_RING deep) so that a group always finds the next set waiting: it stages that set's device work while it
+// tracks the current one, even when another group lags behind and delays the caller.
 struct ftk_group {
     std::unique_ptr<FrontendBackend> be;
     std::unique_ptr<TrackKLTBatch> batch;
@@ -94,7 +95,9 @@ struct ftk_group {
         long long tracked = 0, attempted = 0;
         int rc = FT_OK;
     };
-    Mail mail[2];
+    static constexpr int MAIL_RING = 4;          // power of two
+    static constexpr int PIPE_DEPTH = 2;         // sets that may be in flight behind the one the caller collects
+    Mail mail[MAIL_RING];
     std::thread driver;
 
     // feature-database writer: nothing in tracking depends on the database, so its updates run on their own thread,
@@ -194,12 +197,12 @@ struct ftk_group {
                 sleeping.store(0, std::memory_order_release);
                 if (stop) return;
             }
-            Mail& M = mail[next & 1];
+            Mail& M = mail[next & (MAIL_RING - 1)];
             M.rc = batch->begin(M.ts.data(), M.frames.data());
             // lookahead: if the following set is already in the mailbox, queue its ingest, pyramids and detector now so
             // that the device stays busy while this set's results are processed
             if (M.rc == FT_OK && posted.load(std::memory_order_acquire) > next) {
-                Mail& N = mail[(next + 1) & 1];
+                Mail& N = mail[(next + 1) & (MAIL_RING - 1)];
                 M.rc = batch->stage(N.ts.data(), N.frames.data());
             }
             if (M.rc == FT_OK) M.rc = batch->complete();
@@ -209,10 +212,10 @@ struct ftk_group {
             done.store(next, std::memory_order_release);
         }
     }
-    // hand frame set `seq` (= posted + 1) to the driver; the previous-but-one set must have been collected
+    // hand frame set `seq` (= posted + 1) to the driver; set seq - MAIL_RING + 1 and older must have been collected
     void post(const double* ts, const FrameSource* fr) {
         const long seq = posted.load(std::memory_order_relaxed) + 1;
-        Mail& M = mail[seq & 1];
+        Mail& M = mail[seq & (MAIL_RING - 1)];
         M.ts.assign(ts, ts + n);
         M.frames.assign(fr, fr + n);
         {
@@ -223,7 +226,7 @@ struct ftk_group {
     }
     Mail& wait(long seq) {
         while (done.load(std::memory_order_acquire) < seq) std::this_thread::yield();
-        return mail[seq & 1];
+        return mail[seq & (MAIL_RING - 1)];
     }
 };
 
@@ -454,11 +457,12 @@ int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void*
                              size_t stride, long long* tracked, long long* attempted) {
     if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
     long long tr = 0, at = 0;
-    int rc = b->collect(b->seq - 1, tr, at);   // the mailboxes are two deep: set seq-1 must be out before seq+1 goes in
+    const long depth = ftk_group::PIPE_DEPTH;
+    int rc = b->collect(b->seq - depth, tr, at);   // keeps the mailbox ring from wrapping onto a set still in use
     if (rc != FT_OK) return rc;
     if ((rc = b->fill_frames(frames, frames_on_device, w, h, stride)) != FT_OK) return rc;
     b->post_all(timestamps);
-    rc = b->collect(b->seq - 1, tr, at);       // the set before this one; the new set keeps the groups busy meanwhile
+    rc = b->collect(b->seq - depth, tr, at);       // the newer sets keep the groups busy meanwhile
     if (tracked) *tracked = tr;
     if (attempted) *attempted = at;
     return rc;

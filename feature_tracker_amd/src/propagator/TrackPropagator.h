@@ -41,7 +41,7 @@ public:
     // mean-gyro relative rotation previous->current for cam0/cam1 (TrackPropagator.h:107-153)
     int integrate_by_msckfVio(double lastTime, double currTime, Mat3f& cam0_R_p_c, Mat3f& cam1_R_p_c, bool remove = false) {
         std::lock_guard<std::mutex> lck(mtx_imu);
-        size_t b = 0;
+        size_t b = head;
         while (b < imu_data.size() && (imu_data[b].timestamp - lastTime) < -0.01) b++;
         size_t e = b;
         while (e < imu_data.size() && (imu_data[e].timestamp - currTime) < 0.005) e++;
@@ -52,13 +52,18 @@ public:
         rotation_for(0, mean, dt, cam0_R_p_c);
         rotation_for(1, mean, dt, cam1_R_p_c);
         const int used = (int)(e - b);
-        imu_data.erase(imu_data.begin(), imu_data.begin() + (remove ? e : b));
+        // samples before the window are spent: move the head past them, and compact the buffer only now and then
+        head = remove ? e : b;
+        if (head > 256 && head > imu_data.size() / 2) {
+            imu_data.erase(imu_data.begin(), imu_data.begin() + head);
+            head = 0;
+        }
         return used;
     }
 
     size_t buffered() {
         std::lock_guard<std::mutex> lck(mtx_imu);
-        return imu_data.size();
+        return imu_data.size() - head;
     }
 
 protected:
@@ -84,6 +89,7 @@ protected:
 
     std::mutex mtx_imu;
     std::vector<IMUDATA> imu_data;
+    size_t head = 0;   // first sample not yet spent
     std::map<size_t, Mat3d> R_imu_to_cam;
 };
 

@@ -14,6 +14,9 @@ public:
     virtual ~FrontendBackend() = default;
     virtual int upload(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) = 0;
     virtual int set_frames_device(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride) = 0;
+    // set_frames_device + build_pyramid(with_gradients = 0) as one pass over the frames
+    virtual int set_frames_device_pyramid(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride,
+                                          int max_level, int win_w, int win_h, int* achieved) = 0;
     virtual int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
                               int with_gradients, int* achieved) = 0;
     virtual int lk_track_async(int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) = 0;

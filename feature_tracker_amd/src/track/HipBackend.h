@@ -23,6 +23,10 @@ public:
     int set_frames_device(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride) override {
         return ft_set_frames_device(ctx_, n, streams, slots, dev, w, h, stride);
     }
+    int set_frames_device_pyramid(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride,
+                                  int max_level, int win_w, int win_h, int* achieved) override {
+        return ft_set_frames_device_pyramid(ctx_, n, streams, slots, dev, w, h, stride, max_level, win_w, win_h, achieved);
+    }
     int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h, int with_gradients,
                       int* achieved) override {
         return ft_build_pyramid(ctx_, n, streams, slots, max_level, win_w, win_h, with_gradients, achieved);

@@ -23,26 +23,11 @@ ft_lk_params TrackKLT::lk_params() const {
 void TrackKLT::filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, std::vector<size_t>& ids) {
     size_t o = 0;
     for (size_t i = 0; i < pts.size(); i++) {
-        if (occ.taken(pts[i].pt)) continue;   // too close to an earlier point: drop it (TrackKLT.cpp:238-242)
-        occ.take(pts[i].pt);
-        pts[o] = pts[i]; ids[o] = ids[i];
+        if (!occ.try_take(pts[i].pt)) continue;   // too close to an earlier point: drop it (TrackKLT.cpp:238-242)
+        if (o != i) { pts[o] = pts[i]; ids[o] = ids[i]; }
         o++;
     }
     pts.resize(o); ids.resize(o);
-}
-
-// first num_needed/(grid_x*grid_y)+1 entries of every cell of a ranked detection (Grider_FAST.h:88,:118-130)
-std::vector<KeyPoint> TrackKLT::select_from_detection(const Detection& det, int num_needed, int grid_x, int grid_y) {
-    std::vector<KeyPoint> out;
-    if (!det.valid) return out;
-    const int k = std::min(num_needed / (grid_x * grid_y) + 1, det.per_cell);
-    int off = 0;
-    for (int c = 0; c < det.cells; c++) {
-        const int kept = std::min(det.cell_counts[c], det.per_cell);
-        for (int r = 0; r < kept && r < k && off + r < det.n; r++) out.push_back(Grider_FAST::to_keypoint(det.kps[off + r]));
-        off += kept;
-    }
-    return out;
 }
 
 bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float* H) {
@@ -62,7 +47,9 @@ bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float
 
 void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, MonoPlan& plan) {
     CamState& cs = cams[cam_id];
-    plan = MonoPlan();
+    // reset the plan but keep the capacity of its arrays
+    plan.first = plan.run_lk = plan.reset = plan.use_H = plan.db_pending = false;
+    plan.prev_xy.clear(); plan.next_xy.clear(); plan.err.clear(); plan.status.clear(); plan.db_ids.clear(); plan.db_uvn.clear();
     plan.cam = cam_id;
     plan.timestamp = timestamp;
     plan.stream = stream0 + (int)cam_id;
@@ -82,15 +69,23 @@ int TrackKLT::mono_features_needed(const MonoPlan& plan) {
 }
 
 void TrackKLT::perform_detection_monocular(int cols, int rows, const Detection& det, std::vector<KeyPoint>& pts0, std::vector<size_t>& ids0) {
-    Occupancy occ(cols, rows, min_px_dist);
+    Occupancy& occ = occ_scratch;
+    occ.reset(cols, rows, min_px_dist);
     filter_by_occupancy(occ, pts0, ids0);
     const int num_featsneeded = num_features - (int)pts0.size();
-    if (num_featsneeded > 1) {                                   // "> 1", as TrackKLT.cpp:271
-        for (const KeyPoint& kpt : select_from_detection(det, num_featsneeded, grid_x, grid_y)) {
-            if (occ.taken(kpt.pt)) continue;                     // TrackKLT.cpp:280-288
-            occ.take(kpt.pt);
-            pts0.push_back(kpt);
-            ids0.push_back(++currid);
+    if (num_featsneeded > 1 && det.valid) {                      // "> 1", as TrackKLT.cpp:271
+        // first num_needed/(grid_x*grid_y)+1 entries of every cell of the ranked detection (Grider_FAST.h:88,:118-130)
+        const int k = std::min(num_featsneeded / (grid_x * grid_y) + 1, det.per_cell);
+        int off = 0;
+        for (int c = 0; c < det.cells; c++) {
+            const int kept = std::min(det.cell_counts[c], det.per_cell);
+            for (int r = 0; r < kept && r < k && off + r < det.n; r++) {
+                const KeyPoint kpt = Grider_FAST::to_keypoint(det.kps[off + r]);
+                if (!occ.try_take(kpt.pt)) continue;             // TrackKLT.cpp:280-288
+                pts0.push_back(kpt);
+                ids0.push_back(++currid);
+            }
+            off += kept;
         }
     }
 }
@@ -137,8 +132,9 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
     } else if (plan.reset || !plan.run_lk) {
         pts.clear(); ids.clear();            // lost tracking: re-detect on the next frame (TrackKLT.cpp:118-129)
     } else {
-        std::vector<KeyPoint> good;
-        std::vector<size_t> good_ids;
+        std::vector<KeyPoint>& good = good_scratch;
+        std::vector<size_t>& good_ids = good_ids_scratch;
+        good.clear(); good_ids.clear();
         good.reserve(pts.size()); good_ids.reserve(pts.size());
         for (size_t i = 0; i < pts.size(); i++) {
             const float x = plan.next_xy[2 * i], y = plan.next_xy[2 * i + 1];
@@ -149,10 +145,13 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
             good.push_back(kp);
             good_ids.push_back(ids[i]);
         }
-        if (camera_k.count(plan.cam)) {          // TrackKLT.cpp:187-192: undistort now, write the database in mono_commit
+        const auto k_it = camera_k.find(plan.cam);
+        if (k_it != camera_k.end()) {            // TrackKLT.cpp:187-192: undistort now, write the database in mono_commit
+            const std::array<double, 4>& K = k_it->second;
+            const std::array<double, 4>& Dc = camera_d.at(plan.cam);
             plan.db_uvn.resize(4 * good.size());
             for (size_t i = 0; i < good.size(); i++) {
-                const Point2f npt = undistort_point(good[i].pt, plan.cam);
+                const Point2f npt = undistort_point_brown(good[i].pt, K, Dc);
                 plan.db_uvn[4 * i] = good[i].pt.x; plan.db_uvn[4 * i + 1] = good[i].pt.y;
                 plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
             }

@@ -147,9 +147,20 @@ protected:
         }
         bool taken(const Point2f& p) const { size_t i; return index(p, i) ? cell[i] != 0 : true; }
         void take(const Point2f& p) { size_t i; if (index(p, i)) cell[i] = 1; }
+        // taken() followed by take() with one index computation: true if the cell was free and is now marked
+        bool try_take(const Point2f& p) {
+            size_t i;
+            if (!index(p, i) || cell[i]) return false;
+            cell[i] = 1;
+            return true;
+        }
+        void reset(int cols, int rows, int min_px_dist) {
+            gw = cols / min_px_dist + 2; gh = rows / min_px_dist + 2; dist = min_px_dist;
+            cell.assign((size_t)gw * gh, 0);
+        }
+        Occupancy() = default;
     };
     static void filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, std::vector<size_t>& ids);
-    static std::vector<KeyPoint> select_from_detection(const Detection& det, int num_needed, int grid_x, int grid_y);
     bool gyro_homography(size_t cam_id, double t_last, double t_cur, float* H);
 
     FrontendBackend* be;
@@ -172,6 +183,10 @@ protected:
     float fb_thresh = 1.0f;
     bool speculative_detect = true;
     int slot_ring = 2;
+    // per-tracker scratch reused every frame (no allocation in the steady state)
+    Occupancy occ_scratch;
+    std::vector<KeyPoint> good_scratch;
+    std::vector<size_t> good_ids_scratch;
 
     // per camera: device slot holding the last pyramid (-1 = none), its size and timestamp
     struct CamState {

@@ -69,7 +69,8 @@ public:
     // apply observations taken with take_db; touches only the feature databases, which carry their own locks, so it
     // may run on another thread than begin()/complete() as long as one stream's sets are applied in order
     void commit_db(std::vector<TrackKLT::MonoPlan>& payload) {
-        pool->parallel_for((int)payload.size(), [&](int s) { trackers[s]->mono_commit(payload[s]); });
+        // serial on purpose: the worker pool belongs to the thread that runs begin()/complete()
+        for (size_t s = 0; s < payload.size(); s++) trackers[s]->mono_commit(payload[s]);
     }
     bool in_flight() const { return pending; }
 
@@ -80,6 +81,7 @@ public:
     bool can_stage() const { return ring >= 3 && pending && !staged && size() > 0 && trackers[0]->speculative(); }
     int stage(const double* timestamps, const FrameSource* frames) {
         if (!can_stage()) return FT_OK;
+        const auto t_stage = std::chrono::steady_clock::now();
         const int S = size();
         staged_slots.resize(S);
         for (int s = 0; s < S; s++) staged_slots[s] = trackers[s]->slot_after(plans[s]);
@@ -89,6 +91,8 @@ public:
         staged_ts.assign(timestamps, timestamps + S);
         staged_frames.assign(frames, frames + S);
         staged = true;
+        // the staged set's ingest / pyramid / detector enqueue is booked under the pyramid stage
+        stage_s[ST_PYRAMID] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage).count();
         return FT_OK;
     }
 
@@ -297,10 +301,12 @@ private:
             front_streams[s] = s;   // tracker s owns backend stream s (stream_base = s, camera 0)
             all_dev &= frames[s].dev != nullptr && frames[s].cols == frames[0].cols && frames[s].rows == frames[0].rows && frames[s].step == frames[0].step;
         }
-        if (all_dev) {   // frames already in HBM: one copy launch for the whole batch
+        if (all_dev) {   // frames already in HBM: ingest and pyramids in one pass over the frames
             dev_ptrs.resize(S);
             for (int s = 0; s < S; s++) dev_ptrs[s] = frames[s].dev;
-            if ((rc = be->set_frames_device(S, front_streams.data(), slots.data(), dev_ptrs.data(), frames[0].cols, frames[0].rows, frames[0].step)) != FT_OK) return rc;
+            if (lap) (*lap)(ST_INGEST);
+            if ((rc = be->set_frames_device_pyramid(S, front_streams.data(), slots.data(), dev_ptrs.data(), frames[0].cols, frames[0].rows,
+                                                    frames[0].step, t0.max_level(), t0.window(), t0.window(), nullptr)) != FT_OK) return rc;
         } else {
             for (int s = 0; s < S; s++) {
                 const FrameSource& f = frames[s];
@@ -308,9 +314,9 @@ private:
                 else rc = be->upload(front_streams[s], slots[s], f.host, f.cols, f.rows, f.step);
                 if (rc != FT_OK) return rc;
             }
+            if (lap) (*lap)(ST_INGEST);
+            if ((rc = be->build_pyramid(S, front_streams.data(), slots.data(), t0.max_level(), t0.window(), t0.window(), 0, nullptr)) != FT_OK) return rc;
         }
-        if (lap) (*lap)(ST_INGEST);
-        if ((rc = be->build_pyramid(S, front_streams.data(), slots.data(), t0.max_level(), t0.window(), t0.window(), 0, nullptr)) != FT_OK) return rc;
         D.who.clear();
         if (detect) {
             const int gx = t0.grid_cols(), gy = t0.grid_rows(), kmax = t0.per_cell_max();

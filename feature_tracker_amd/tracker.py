@@ -188,7 +188,8 @@ class BatchTracker(_Base):
         h, w = keep[0].shape
         for i, f in enumerate(keep):
             self._ptrs[i] = f.ctypes.data
-        self._keep_prev, self._keep = getattr(self, "_keep", None), keep   # a pipelined set completes one call later
+        # a pipelined set may complete up to three calls later: keep the arrays of the last four sets alive
+        self._keep = (getattr(self, "_keep", []) + [keep])[-4:]
         return self._feed(timestamps, 0, w, h, keep[0].strides[0], pipelined)
 
     def feed_device(self, timestamps, dev_ptrs, w, h, stride, pipelined=False):

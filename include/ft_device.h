@@ -107,6 +107,12 @@ int ft_set_frame_device(ft_ctx* ctx, int stream, int slot, const void* dev, int 
 /* n device-resident frames of one size into n slots with a single copy launch */
 int ft_set_frames_device(ft_ctx* ctx, int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride);
 
+/* ft_set_frames_device followed by ft_build_pyramid(with_gradients = 0) in one pass over the frames: level 0 and
+ * level 1 are written while each frame is read once (the clone() + buildOpticalFlowPyramid pair at
+ * src/track/TrackKLT.cpp:46-56). Asynchronous; the frames must stay valid until the next ft_sync / ft_wait. */
+int ft_set_frames_device_pyramid(ft_ctx* ctx, int n, const int* streams, const int* slots, const void* const* dev, int w, int h,
+                                 size_t stride, int max_level, int win_w, int win_h, int* achieved);
+
 /* Levels 1..max_level by pyrDown and, if with_gradients, Scharr (Ix,Iy) of every level, for n images in one
  * launch per level.  achieved[i] (optional) receives the top level index after the early-stop rule of
  * buildOpticalFlowPyramid (stop when the next level would not exceed the window). Asynchronous. */

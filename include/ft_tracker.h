@@ -68,9 +68,10 @@ int ftk_batch_feed_imu(ftk_batch* b, int stream, double timestamp, const double*
  * tracked/attempted (optional) receive the number of features with final status 1 / handed to LK. */
 int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                    size_t stride, long long* tracked, long long* attempted);
-/* Pipelined feed for sustained throughput: posts this frame set to the groups and returns once the PREVIOUS set is
- * complete, so the groups never idle between sets.  tracked/attempted count the set completed by this call;
- * ftk_batch_flush completes the last one.  Frames must stay valid until their set is complete. */
+/* Pipelined feed for sustained throughput: posts this frame set to the groups and returns once the set posted two
+ * calls earlier is complete, so every group always finds its next set waiting (it queues that set's device work while
+ * it still tracks the current one).  tracked/attempted count the sets completed by this call; ftk_batch_flush
+ * completes the rest.  Frames must stay valid until their set is complete (at most three calls, or a flush, later). */
 int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void* const* frames, int frames_on_device, int w, int h,
                              size_t stride, long long* tracked, long long* attempted);
 int ftk_batch_flush(ftk_batch* b, long long* tracked, long long* attempted);

@@ -70,6 +70,36 @@ def test_pyramid_batched_streams(dev):
                 assert np.array_equal(ctx.download_grad(i, 1, l), O.scharr(ref.level(l)))
 
 
+@pytest.mark.parametrize("shape,win,max_level,pad", [((480, 752), 21, 3, 0), ((479, 751), 15, 3, 5), ((33, 47), 5, 2, 1), ((100, 80), 21, 5, 0),
+                                                      ((257, 129), 9, 4, 3), ((8, 300), 3, 1, 7), ((720, 1280), 21, 4, 0), ((40, 7), 3, 2, 2)])
+def test_ingest_pyramid_single_pass_bit_exact(dev, shape, win, max_level, pad):
+    """Frames already in HBM (any row stride and alignment): level 0 and the pyramid come out of one pass."""
+    import torch
+    h, w = shape
+    rng = np.random.default_rng(11)
+    imgs = [synth.texture(w, h, seed=61) if min(shape) > 16 else rng.integers(0, 256, shape, dtype=np.uint8),
+            rng.integers(0, 256, shape, dtype=np.uint8)]
+    # rows with a stride that is not a multiple of anything convenient, starting at an odd byte offset
+    stride = w + pad
+    flat = torch.zeros(2 * h * stride + 64, dtype=torch.uint8, device="cuda")
+    ptrs = []
+    for i, im in enumerate(imgs):
+        padded = np.zeros((h, stride), np.uint8)
+        padded[:, :w] = im
+        off = 1 + i * h * stride if pad else i * h * stride
+        flat[off:off + h * stride] = torch.from_numpy(padded.reshape(-1)).cuda()
+        ptrs.append(flat.data_ptr() + off)
+    torch.cuda.synchronize()
+    with _ctx(dev, w, h) as ctx:
+        ach = ctx.set_frames_device_pyramid([0, 1], [1, 0], ptrs, w, h, stride, max_level, win)
+        ctx.sync()
+        for i, im in enumerate(imgs):
+            ref = O.Pyramid(im, win, max_level)
+            assert ach[i] == ref.levels - 1
+            for l in range(ref.levels):
+                assert np.array_equal(ctx.download_level(i, 1 - i, l), ref.level(l)), f"image {i} level {l}"
+
+
 def _compare_lk(gpu, ref, min_agree=STATUS_AGREE):
     g_xy, g_st, g_err = gpu[:3]
     r_xy, r_st, r_err = ref[:3]
