@@ -686,7 +686,7 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     int* surv_dev = kept_dev + (size_t)n * cells;
     EventPair ep;
     prof_begin(c, 2, ep);
-    const int tiles = ((w + FD_TX - 1) / FD_TX) * ((h + FD_TY - 1) / FD_TY);
+    const int tiles = fast_tiles_x(w) * fast_tiles_y(h);
     hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(256), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
     hipLaunchKernelGGL(fast_topk_kernel, dim3(n * cells), dim3(256), 0, c->q, G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev);
     prof_end(c, ep);

@@ -6,7 +6,9 @@
 // therefore zero outside the cell insets, and a single image-wide 3x3 strict-maximum test equals per-cell NMS.
 //
 //   fast_detect_kernel : u8 image -> per-cell candidate lists (score + position keys, unordered); reads level 0
-//                        once, keeps pixels and scores in LDS, one global atomic per NMS survivor.
+//                        once, keeps pixels and scores in LDS, one global atomic per NMS survivor.  The kernel is
+//                        bound by vector-instruction issue, so the pre-test handles four pixels per lane from
+//                        dword LDS reads and the exact strength runs only on compacted candidates.
 //   fast_topk_kernel   : one workgroup per cell extracts the first `per_cell` candidates in the total order
 //                        (score desc, y asc, x asc).
 #pragma once
@@ -49,64 +51,111 @@ __device__ inline uint32_t fast_key(int score, int ly, int lx) {
     return ((uint32_t)score << 24) | ((uint32_t)(4095 - ly) << 12) | (uint32_t)(4095 - lx);
 }
 
-constexpr int FD_TX = 64, FD_TY = 16;            // output tile
-constexpr int FD_PW = FD_TX + 8, FD_PH = FD_TY + 8;   // pixel tile: 4-pixel apron (3 for the circle + 1 for NMS)
-constexpr int FD_SW = FD_TX + 2, FD_SH = FD_TY + 2;   // score tile: 1-pixel apron
-constexpr int FD_SPITCH = 68;
+// Detector tile geometry.  A workgroup reports the corners of a 60x30 output region whose first column is 2 mod 4
+// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x32
+// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 30: exactly 16 dwords x 32
+// rows = two 4-pixel tasks per thread, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the
+// radius of the circle and is staged from column CX0 - 8 in 8-byte groups.
+constexpr int FD_OW = 60, FD_OH = 30;            // output region
+constexpr int FD_CW = 64, FD_CH = 32;            // score container
+constexpr int FD_PPITCH = 80;                    // pixel tile row: columns CX0-8 .. CX0+71
+constexpr int FD_PROWS = FD_CH + 6;              // rows OY-4 .. OY+33
+constexpr int FD_GROUPS = FD_PPITCH / 8;         // 8-byte groups per pixel row
+constexpr int FD_LIST = FD_CW * FD_CH;           // candidate list capacity
 
-// Fused detector: one 256-thread workgroup owns a 64x16 tile.  The pixel tile is staged in LDS once; a cheap
-// compass test compacts the candidates; the exact corner strength is evaluated only for those (dense lanes);
-// strict 3x3 maxima of the LDS score tile go straight to the per-cell candidate lists.  No score map in HBM.
+struct __attribute__((packed)) FdU2Unaligned { uint32_t a, b; };
+
+__host__ __device__ inline int fast_tiles_x(int w) { return (max(w - 2, 1) + FD_OW - 1) / FD_OW; }
+__host__ __device__ inline int fast_tiles_y(int h) { return (h + FD_OH - 1) / FD_OH; }
+
+// Fused detector: the pixel tile is staged in LDS once; a cheap compass test on four pixels per lane compacts the
+// candidates; the exact corner strength is evaluated only for those (dense lanes); strict 3x3 maxima of the LDS score
+// tile go straight to the per-cell candidate lists.  No score map in HBM.
 __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L, FastGrid G, uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
-    __shared__ __attribute__((aligned(16))) uint8_t pix[FD_PH * FD_PW];
-    __shared__ uint8_t sc[FD_SH * FD_SPITCH];
-    __shared__ uint16_t list[FD_SW * FD_SH];
-    __shared__ uint8_t col_ok[FD_SW], row_ok[FD_SH];   // column / row lies in the inset of some cell
+    __shared__ __attribute__((aligned(16))) uint8_t pix[FD_PROWS * FD_PPITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FD_CH * FD_CW];
+    __shared__ uint16_t list[FD_LIST];
+    __shared__ __attribute__((aligned(4))) uint8_t col_ok[FD_CW];   // column lies in the inset of some cell
+    __shared__ uint8_t row_ok[FD_CH];                               // row lies in the inset of some cell
     __shared__ int list_n;
     const int t = threadIdx.x;
     // work list: (image, tile row, tile column), images outermost
-    const int tiles_x = (G.w + FD_TX - 1) / FD_TX, tiles_y = (G.h + FD_TY - 1) / FD_TY;
+    const int tiles_x = fast_tiles_x(G.w), tiles_y = fast_tiles_y(G.h);
     const int item = xcd_item(blockIdx.x, tiles_x * tiles_y * L.n);
     if (item >= tiles_x * tiles_y * L.n) return;
     const int img_i = item / (tiles_x * tiles_y), tile_i = item - img_i * (tiles_x * tiles_y);
     const int slot = L.idx[img_i];
-    const int X0 = (tile_i % tiles_x) * FD_TX, Y0 = (tile_i / tiles_x) * FD_TY;
+    const int CX0 = (tile_i % tiles_x) * FD_OW, OY = (tile_i / tiles_x) * FD_OH;
     const uint8_t* __restrict__ img = level_img(A, slot, 0);
     const uint32_t pitch = A.lv[0].img_pitch;
 
-    // ---- stage pixels: 24 rows x 18 dwords; coordinates are clamped (only insets are ever evaluated, and an
-    //      inset pixel's circle lies inside the image) ----
-    for (int i = t; i < FD_PH * (FD_PW / 4); i += 256) {
-        const int rr = i / (FD_PW / 4), d = i - rr * (FD_PW / 4);
-        const int gy = min(max(Y0 - 4 + rr, 0), G.h - 1);
-        const int gxd = min(max((X0 - 4) / 4 + d, 0), (int)(pitch / 4) - 1);
-        reinterpret_cast<uint32_t*>(pix)[rr * (FD_PW / 4) + d] = reinterpret_cast<const uint32_t*>(img + (size_t)gy * pitch)[gxd];
+    // ---- stage pixels: a wavefront load covers 6 rows x 10 groups of 8 bytes; 2 rounds x 4 waves = 48 rows.
+    //      Rows are clamped into the image and the group left of the image is clamped to column 0: only insets are
+    //      ever evaluated, and an inset pixel's circle lies inside the image.  Columns past the row end read on
+    //      into the next row of the plane (never used). ----
+    {
+        const int lane = t & 63, wv = t >> 6;
+        const int rg = lane / FD_GROUPS, c8 = lane - rg * FD_GROUPS;
+        const int gx = max(CX0 - 8 + 8 * c8, 0);
+        uint2 v[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int row = min(wv * 6 + rg + 24 * k, FD_PROWS - 1);
+            const int gy = min(max(OY - 4 + row, 0), G.h - 1);
+            const FdU2Unaligned u = *reinterpret_cast<const FdU2Unaligned*>(img + ((uint32_t)gy * pitch + (uint32_t)gx));
+            v[k] = make_uint2(u.a, u.b);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int row = wv * 6 + rg + 24 * k;
+            if (lane < 6 * FD_GROUPS && row < FD_PROWS) *reinterpret_cast<uint2*>(&pix[row * FD_PPITCH + 8 * c8]) = v[k];
+        }
     }
-    for (int i = t; i < FD_SH * FD_SPITCH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    reinterpret_cast<uint2*>(sc)[t] = make_uint2(0u, 0u);   // 256 threads x 8 bytes = the whole score tile
     if (t == 0) list_n = 0;
-    // cell membership is separable: one division per column and per row of the tile instead of two per pixel
-    if (t < FD_SW) {
-        const int gx = X0 - 1 + t;
-        const int cxi = gx >= 0 ? gx / G.size_x : 0, lx = gx - cxi * G.size_x;
-        col_ok[t] = (gx >= 0 && gx < G.w && cxi < G.ct_cols && lx >= 3 && lx < G.size_x - 3) ? 1 : 0;
-    } else if (t >= 128 && t < 128 + FD_SH) {
-        const int gy = Y0 - 1 + (t - 128);
+    // cell membership is separable: one division per column and per row of the container instead of two per pixel
+    if (t < FD_CW) {
+        const int gx = CX0 + t;
+        const int cxi = gx / G.size_x, lx = gx - cxi * G.size_x;
+        col_ok[t] = (gx < G.w && cxi < G.ct_cols && lx >= 3 && lx < G.size_x - 3) ? 1 : 0;
+    } else if (t >= 128 && t < 128 + FD_CH) {
+        const int gy = OY - 1 + (t - 128);
         const int cyi = gy >= 0 ? gy / G.size_y : 0, ly = gy - cyi * G.size_y;
         row_ok[t - 128] = (gy >= 0 && gy < G.h && cyi < G.ct_rows && ly >= 3 && ly < G.size_y - 3) ? 1 : 0;
     }
     __syncthreads();
 
-    // ---- compass test on the 66x18 score region: a 9-arc holds one pixel of every opposite pair ----
+    // ---- compass test, four pixels per task: a 9-arc holds one pixel of every opposite pair ----
     const int thr = G.threshold;
-    for (int i = t; i < FD_SW * FD_SH; i += 256) {
-        const int sj = i / FD_SW, si = i - sj * FD_SW;
-        if (!(col_ok[si] & row_ok[sj])) continue;
-        const uint8_t* p = &pix[(sj + 3) * FD_PW + si + 3];
-        const int v = p[0], lo = v - thr, hi = v + thr;
-        const int p0 = p[3 * FD_PW], p8 = p[-3 * FD_PW], p4 = p[3], p12 = p[-3];
-        const bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
-        const bool bright = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
-        if (dark || bright) list[atomicAdd(&list_n, 1)] = (uint16_t)i;
+    const int d = t & 15;                                                    // container dword column of this thread
+    const uint32_t colmask = *reinterpret_cast<const uint32_t*>(&col_ok[4 * d]);   // one byte per column
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        const int r = (t >> 4) + 16 * round;                                 // container row
+        uint32_t hits = 0;
+        if (colmask != 0 && row_ok[r]) {
+            const uint8_t* p = &pix[(r + 3) * FD_PPITCH + 8 + 4 * d];
+            const uint32_t C = *reinterpret_cast<const uint32_t*>(p);
+            const uint32_t Wd = *reinterpret_cast<const uint32_t*>(p - 4), Ed = *reinterpret_cast<const uint32_t*>(p + 4);
+            const uint32_t N = *reinterpret_cast<const uint32_t*>(p - 3 * FD_PPITCH), S = *reinterpret_cast<const uint32_t*>(p + 3 * FD_PPITCH);
+            const uint64_t we = ((uint64_t)C << 32) | Wd, ce = ((uint64_t)Ed << 32) | C;   // bytes x-4..x+3 and x..x+7
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int v = (C >> (8 * j)) & 0xff, lo = v - thr, hi = v + thr;
+                const int n = (N >> (8 * j)) & 0xff, s = (S >> (8 * j)) & 0xff;
+                const int w3 = (int)((we >> (8 * (j + 1))) & 0xff);          // pixel x+j-3
+                const int e3 = (int)((ce >> (8 * (j + 3))) & 0xff);          // pixel x+j+3
+                const bool dark = (n < lo || s < lo) && (e3 < lo || w3 < lo);
+                const bool bright = (n > hi || s > hi) && (e3 > hi || w3 > hi);
+                if ((dark || bright) && ((colmask >> (8 * j)) & 1)) hits |= 1u << j;
+            }
+        }
+        if (hits) {
+            int at = atomicAdd(&list_n, __builtin_popcount(hits));
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (hits & (1u << j)) list[at++] = (uint16_t)((r << 6) | (4 * d + j));
+        }
     }
     __syncthreads();
 
@@ -114,34 +163,39 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     const int n_list = list_n;
     for (int c = t; c < n_list; c += 256) {
         const int i = list[c];
-        const int sj = i / FD_SW, si = i - sj * FD_SW;
-        const uint8_t* p = &pix[(sj + 3) * FD_PW + si + 3];
+        const int sj = i >> 6, si = i & 63;
+        const uint8_t* p = &pix[(sj + 3) * FD_PPITCH + 8 + si];
         const int v = p[0];
-        int d[16];
-        d[0] = v - p[3 * FD_PW];      d[1] = v - p[3 * FD_PW + 1];   d[2] = v - p[2 * FD_PW + 2];   d[3] = v - p[FD_PW + 3];
-        d[4] = v - p[3];              d[5] = v - p[-FD_PW + 3];      d[6] = v - p[-2 * FD_PW + 2];  d[7] = v - p[-3 * FD_PW + 1];
-        d[8] = v - p[-3 * FD_PW];     d[9] = v - p[-3 * FD_PW - 1];  d[10] = v - p[-2 * FD_PW - 2]; d[11] = v - p[-FD_PW - 3];
-        d[12] = v - p[-3];            d[13] = v - p[FD_PW - 3];      d[14] = v - p[2 * FD_PW - 2];  d[15] = v - p[3 * FD_PW - 1];
-        const int s = fast_strength(d);
-        if (s > thr) sc[sj * FD_SPITCH + si] = (uint8_t)(s - 1);
+        int dd[16];
+        dd[0] = v - p[3 * FD_PPITCH];      dd[1] = v - p[3 * FD_PPITCH + 1];   dd[2] = v - p[2 * FD_PPITCH + 2];   dd[3] = v - p[FD_PPITCH + 3];
+        dd[4] = v - p[3];                  dd[5] = v - p[-FD_PPITCH + 3];      dd[6] = v - p[-2 * FD_PPITCH + 2];  dd[7] = v - p[-3 * FD_PPITCH + 1];
+        dd[8] = v - p[-3 * FD_PPITCH];     dd[9] = v - p[-3 * FD_PPITCH - 1];  dd[10] = v - p[-2 * FD_PPITCH - 2]; dd[11] = v - p[-FD_PPITCH - 3];
+        dd[12] = v - p[-3];                dd[13] = v - p[FD_PPITCH - 3];      dd[14] = v - p[2 * FD_PPITCH - 2];  dd[15] = v - p[3 * FD_PPITCH - 1];
+        const int s = fast_strength(dd);
+        if (s > thr) sc[sj * FD_CW + si] = (uint8_t)(s - 1);
     }
     __syncthreads();
 
-    // ---- strict 3x3 maxima -> per-cell candidate lists ----
+    // ---- strict 3x3 maxima of the output region (container rows 1..30, columns 2..61) -> per-cell candidate lists ----
     const int cells = G.ct_cols * G.ct_rows;
 #pragma unroll
-    for (int r = 0; r < FD_TY / 4; r++) {
-        const int ox = t & 63, oy = (t >> 6) + 4 * r;
-        const uint8_t* q = &sc[(oy + 1) * FD_SPITCH + ox + 1];
-        const int s = q[0];
-        if (s == 0) continue;   // a score of 0 can never be a strict maximum
-        if (s > q[-1] && s > q[1] && s > q[-FD_SPITCH - 1] && s > q[-FD_SPITCH] && s > q[-FD_SPITCH + 1] &&
-            s > q[FD_SPITCH - 1] && s > q[FD_SPITCH] && s > q[FD_SPITCH + 1]) {
-            const int gx = X0 + ox, gy = Y0 + oy;
-            const int cxi = gx / G.size_x, cyi = gy / G.size_y;
-            const int gcell = img_i * cells + cyi * G.ct_cols + cxi;
-            const int at = atomicAdd(&cand_count[gcell], 1);
-            if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
+    for (int round = 0; round < 2; round++) {
+        const int r = 1 + (t >> 4) + 16 * round;
+        if (r > FD_OH) continue;
+        const uint32_t S4 = *reinterpret_cast<const uint32_t*>(&sc[r * FD_CW + 4 * d]);
+        if (S4 == 0) continue;                       // a score of 0 can never be a strict maximum
+        for (int j = 0; j < 4; j++) {
+            const int s = (S4 >> (8 * j)) & 0xff, col = 4 * d + j;
+            if (s == 0 || col < 2 || col > FD_OW + 1) continue;
+            const uint8_t* q = &sc[r * FD_CW + col];
+            if (s > q[-1] && s > q[1] && s > q[-FD_CW - 1] && s > q[-FD_CW] && s > q[-FD_CW + 1] &&
+                s > q[FD_CW - 1] && s > q[FD_CW] && s > q[FD_CW + 1]) {
+                const int gx = CX0 + col, gy = OY - 1 + r;
+                const int cxi = gx / G.size_x, cyi = gy / G.size_y;
+                const int gcell = img_i * cells + cyi * G.ct_cols + cxi;
+                const int at = atomicAdd(&cand_count[gcell], 1);
+                if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
+            }
         }
     }
 }
