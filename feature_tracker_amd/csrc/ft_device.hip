@@ -76,13 +76,15 @@ struct ft_ctx {
 
     // LK staging
     uint8_t* lk_in_host = nullptr;  uint8_t* lk_in_dev = nullptr;  size_t lk_in_bytes = 0;
+    uint8_t* lk_in_host_dev = nullptr;    // device-side address of lk_in_host
     uint8_t* lk_out_host = nullptr; uint8_t* lk_out_dev = nullptr; size_t lk_out_bytes = 0;
+    uint8_t* lk_out_host_dev = nullptr;   // device-side address of lk_out_host
     PendingLK lk_pending;
 
     // FAST scratch
     uint32_t* cand = nullptr; size_t cand_entries_per_img = 0;
     int* cand_count = nullptr;          // [n_streams][max_grid_cells]
-    uint8_t* fast_out_dev = nullptr;    // one block per call: keypoints, kept counts, survivor counts (one D2H copy)
+    uint8_t* fast_out_host_dev[2] = {nullptr, nullptr};   // device-side addresses of the pinned result buffers
     // detector outputs are double-buffered on the host side so that the detector of the next frame set can be
     // enqueued before the previous set's outputs have been delivered
     static constexpr int FAST_RING = 2;
@@ -346,14 +348,24 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
 
     // LK staging
     const size_t N = (size_t)lim->max_points;
-    c->lk_in_bytes = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256) + align_up(2 * N, 256) + 2 * align_up(8 * N, 256);
+    c->lk_in_bytes = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256) + align_up(2 * N, 256) + 2 * align_up(8 * N, 256) + 256;
     c->lk_out_bytes = align_up(13 * N, 16) + sizeof(int) * N * FT_MAX_LEVELS + 256;
     if (hipHostMalloc(&p, c->lk_in_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_in_host = (uint8_t*)p;
+    {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(FT_E_HIP);
+        c->lk_in_host_dev = (uint8_t*)dp;
+    }
     if (hipMalloc(&p, c->lk_in_bytes) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_in_dev = (uint8_t*)p;
     if (hipHostMalloc(&p, c->lk_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_out_host = (uint8_t*)p;
+    {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(FT_E_HIP);
+        c->lk_out_host_dev = (uint8_t*)dp;
+    }
     if (hipMalloc(&p, c->lk_out_bytes) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_out_dev = (uint8_t*)p;
 
@@ -367,11 +379,12 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     // the per-cell candidate counters start at zero and every top-k pass leaves them at zero again
     if (hipMemset(c->cand_count, 0, sizeof(int) * cells_total) != hipSuccess) return fail(FT_E_HIP);
     c->fast_out_bytes = align_up(sizeof(ft_keypoint) * cells_total * lim->max_per_cell, 16) + sizeof(int) * cells_total * 2 + 256;
-    if (hipMalloc(&p, c->fast_out_bytes) != hipSuccess) return fail(FT_E_NOMEM);
-    c->fast_out_dev = (uint8_t*)p;
     for (int i = 0; i < ft_ctx::FAST_RING; i++) {
         if (hipHostMalloc(&p, c->fast_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
         c->fast_out_host[i] = (uint8_t*)p;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(FT_E_HIP);
+        c->fast_out_host_dev[i] = (uint8_t*)dp;
     }
     for (auto& f : c->fences)
         if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) return fail(FT_E_HIP);
@@ -404,7 +417,6 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->cand) (void)hipFree(c->cand);
     if (c->cand_count) (void)hipFree(c->cand_count);
-    if (c->fast_out_dev) (void)hipFree(c->fast_out_dev);
     for (auto& h : c->fast_out_host) if (h) (void)hipHostFree(h);
     for (auto& f : c->fences) if (f.ev) (void)hipEventDestroy(f.ev);
     if (c->pf_dev) (void)hipFree(c->pf_dev);
@@ -595,8 +607,12 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     }
     if (N == 0) return FT_OK;
 
-    // one H2D copy for the whole block (jobs .. end of next_xy in use)
-    FT_HIP(c, hipMemcpyAsync(c->lk_in_dev, hb, off_next + 8 * N, hipMemcpyHostToDevice, c->q));
+    // one transfer for the whole block (jobs .. end of next_xy in use)
+    {
+        const int n16 = (int)((off_next + 8 * N + 15) / 16);
+        hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->q, reinterpret_cast<const uint4*>(c->lk_in_host_dev),
+                           reinterpret_cast<uint4*>(c->lk_in_dev), n16);
+    }
 
     LKArgs a;
     a.A = c->arena;
@@ -604,7 +620,10 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.pt_job = reinterpret_cast<const uint16_t*>(c->lk_in_dev + off_ptjob);
     a.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);
     a.guess_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_next);
-    uint8_t* ob = c->lk_out_dev;
+    // Without a backward pass (which reads the forward results on the device) and without iteration counters, lane 0
+    // of every wave writes its 13 result bytes straight into the pinned host block: no copy command to enqueue.
+    const bool direct_out = !fb && !want_iters;
+    uint8_t* ob = direct_out ? c->lk_out_host_dev : c->lk_out_dev;
     a.next_xy = reinterpret_cast<float*>(ob);
     a.err = reinterpret_cast<float*>(ob + 8 * N);
     a.status = ob + 12 * N;
@@ -637,8 +656,10 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
 
-    const size_t out_bytes = align_up(13 * N, 16) + (want_iters ? sizeof(int) * N * nlev : 0);
-    FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, c->q));
+    if (!direct_out) {
+        const size_t out_bytes = align_up(13 * N, 16) + (want_iters ? sizeof(int) * N * nlev : 0);
+        FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, c->q));
+    }
 
     PendingLK& P = c->lk_pending;
     P.jobs.assign(jobs, jobs + n_jobs);
@@ -679,10 +700,12 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
         rc = sync_and_deliver(c);
         if (rc) return rc;
     }
+    // the top-k kernel writes its (small) results straight into the pinned host buffer: no copy command to enqueue
     const size_t kp_bytes = sizeof(ft_keypoint) * (size_t)n * cells * per_cell;
     const size_t cnt_off = align_up(kp_bytes, 16);
-    ft_keypoint* kp_dev = reinterpret_cast<ft_keypoint*>(c->fast_out_dev);
-    int* kept_dev = reinterpret_cast<int*>(c->fast_out_dev + cnt_off);
+    uint8_t* out_block = c->fast_out_host_dev[ring];
+    ft_keypoint* kp_dev = reinterpret_cast<ft_keypoint*>(out_block);
+    int* kept_dev = reinterpret_cast<int*>(out_block + cnt_off);
     int* surv_dev = kept_dev + (size_t)n * cells;
     EventPair ep;
     prof_begin(c, 2, ep);
@@ -692,7 +715,6 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
     // cand is indexed [image*cells + cell][cand_cap], the keypoints [image*cells + cell][per_cell]
-    FT_HIP(c, hipMemcpyAsync(c->fast_out_host[ring], c->fast_out_dev, cnt_off + sizeof(int) * 2 * (size_t)n * cells, hipMemcpyDeviceToHost, c->q));
     PendingFast& F = c->fast_pending[ring];
     F.active = true; F.seq = ++c->seq; F.n = n; F.cells = cells; F.per_cell = per_cell; F.cap = cap;
     F.out = out; F.n_out = n_out; F.cell_counts = cell_counts;

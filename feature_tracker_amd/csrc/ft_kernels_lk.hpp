@@ -525,6 +525,13 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     }
 }
 
+// input block of a tracking batch: pinned host memory (read through its device address) -> device memory, 16 bytes
+// per lane.  A kernel instead of a copy command: enqueueing it never waits on the copy path of the runtime.
+__global__ void __launch_bounds__(256) fetch_block_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 // standalone point warp p' = pi(H * [p;1]) (gyro-predicted flow)
 __global__ void __launch_bounds__(256) predict_flow_kernel(const float* __restrict__ H9, const float* __restrict__ xy, float* __restrict__ out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -154,7 +154,7 @@ struct ftk_group {
             std::lock_guard<std::mutex> lk(wm);
             target = w_posted;
         }
-        while (w_done.load(std::memory_order_acquire) < target) std::this_thread::yield();
+        while (w_done.load(std::memory_order_acquire) < target) std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     std::mutex m;
     std::condition_variable cv;
@@ -187,9 +187,10 @@ struct ftk_group {
     void run() {
         for (;;) {
             const long next = done.load(std::memory_order_relaxed) + 1;
-            // stay hot between back-to-back frames; sleep when the caller goes quiet
-            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
-            while (posted.load(std::memory_order_acquire) < next && std::chrono::steady_clock::now() < spin_until) {}
+            // a short spin bridges back-to-back frames; after that sleep: a thread that spins for long steals issue
+            // slots from whatever shares its core (the other group's driver, the HIP runtime's own threads)
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
+            while (posted.load(std::memory_order_acquire) < next && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
             if (posted.load(std::memory_order_acquire) < next) {
                 std::unique_lock<std::mutex> lk(m);
                 sleeping.store(1, std::memory_order_release);
@@ -209,7 +210,12 @@ struct ftk_group {
             post_db();   // this set's observations go to the database on the writer thread
             M.tracked = (long long)batch->tracked_features();
             M.attempted = (long long)batch->attempted_features();
-            done.store(next, std::memory_order_release);
+            // sequentially consistent store/load pair: either the waiter sees `done` or this thread sees the waiter
+            done.store(next);
+            if (waiters.load()) {
+                std::lock_guard<std::mutex> lk(dm);
+                dcv.notify_all();
+            }
         }
     }
     // hand frame set `seq` (= posted + 1) to the driver; set seq - MAIL_RING + 1 and older must have been collected
@@ -224,8 +230,19 @@ struct ftk_group {
         }
         if (sleeping.load(std::memory_order_acquire)) cv.notify_all();
     }
+    // caller side: block until set `seq` is complete (short spin first, then sleep on the condition variable)
+    std::mutex dm;
+    std::condition_variable dcv;
+    std::atomic<int> waiters{0};
     Mail& wait(long seq) {
-        while (done.load(std::memory_order_acquire) < seq) std::this_thread::yield();
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
+        while (done.load(std::memory_order_acquire) < seq && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
+        if (done.load(std::memory_order_acquire) < seq) {
+            std::unique_lock<std::mutex> lk(dm);
+            waiters.fetch_add(1);
+            dcv.wait(lk, [&] { return done.load() >= seq; });
+            waiters.fetch_sub(1, std::memory_order_acq_rel);
+        }
         return mail[seq & (MAIL_RING - 1)];
     }
 };
