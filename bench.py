@@ -39,9 +39,13 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
-# HBM bytes per launch group from rocprofv3 PMC passes (TCC_EA0_RDREQ / WRREQ families, collected in separate runs
-# and corrected for gfx950 as the summaries under profiles/ describe); None where no pass has been made
-MEASURED_TRAFFIC = {}
+# HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
+# doubled as gfx950 requires; profiles/r1_f_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
+MEASURED_TRAFFIC = {
+    ("cfg4", "lk_track"): (5817.3 + 19.9, "point"),
+    ("cfg4", "pyramid"): (363195.0 + 460832.0 + 126840.5 + 28800.0, "frame"),
+    ("cfg4", "fast_grid"): (373083.6 + 16715.2 + 6580.3 + 5017.0, "frame"),
+}
 
 
 def level_sizes(w, h, max_level):
@@ -244,8 +248,12 @@ def main():
         # the roofline entry describes the kernel group that takes the most device time per step
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
         pk = per_kernel.get(dom, {})
+        units = {"point": kt.lk_points / max(1, kt.lk_launches), "frame": float(S)}
+        for name, e in per_kernel.items():
+            m = MEASURED_TRAFFIC.get((args.workload, name)) if not args.host_frames else None
+            e["hbm_traffic_bytes"] = m[0] * units[m[1]] if m else None
         roofline = dict(kernel=kernel_names.get(dom), bound="hbm", achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=pk.get("frac_hbm_peak"), traffic=MEASURED_TRAFFIC.get((args.workload, dom)),
+                        unit="GB/s", frac=pk.get("frac_hbm_peak"), traffic=pk.get("hbm_traffic_bytes"),
                         avg_launch_ms=pk.get("avg_ms"), algorithmic_bytes_per_launch=pk.get("algorithmic_bytes"))
         out = {
             "metric": "tracked_features_per_sec", "value": tracked_all / dt_max, "unit": "features/s", "n_gpus": world,
