@@ -1,0 +1,55 @@
+"""Generates tests/golden/frontend_golden.npz from the CPU oracle (tests/oracle_lib.py).
+
+The reference cannot be built here (it needs OpenCV 3, Eigen and Boost) and holds no test vectors, so these vectors pin
+the oracle's own output: they catch drift of the oracle and give the GPU tests fixed expected values that do not
+depend on the oracle being rebuilt.  Run from the repository root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle_lib as O   # noqa: E402
+
+W, H, WIN, MAX_LEVEL = 160, 112, 15, 2
+
+
+def build():
+    # two consecutive frames of the synthetic camera motion (sub-pixel translation, slight rotation, sensor noise)
+    from feature_tracker_amd import synth as seq_synth
+    frames = seq_synth.Sequence(W, H, 2, stream_id=5).frames
+    prev, nxt = np.ascontiguousarray(frames[0]), np.ascontiguousarray(frames[1])
+    out = {"prev": prev, "next": nxt, "win": np.int32(WIN), "max_level": np.int32(MAX_LEVEL)}
+    pp, pn = O.Pyramid(prev, WIN, MAX_LEVEL), O.Pyramid(nxt, WIN, MAX_LEVEL)
+    out["levels"] = np.int32(pp.levels)
+    for l in range(pp.levels):
+        out[f"prev_level{l}"] = pp.level(l)
+        out[f"prev_grad{l}"] = O.scharr(pp.level(l))
+    kps = O.grid_fast(prev, 120, 4, 3, 12)
+    out["fast_grid_4x3_need120_thr12"] = kps
+    pts = np.ascontiguousarray(kps[:, :2], dtype=np.float32)
+    # some points near and beyond the border, and one on a flat patch, for the status paths
+    extra = np.array([[1.5, 2.5], [W - 2.0, H - 3.0], [-20.0, 10.0], [W + 30.0, 5.0]], dtype=np.float32)
+    pts = np.concatenate([pts, extra])
+    xy, st, er, it = O.lk_track(pp, pn, pts, win=WIN, max_level=MAX_LEVEL, want_iters=True)
+    out["lk_prev_xy"], out["lk_next_xy"], out["lk_status"], out["lk_err"], out["lk_iters"] = pts, xy, st, er, it
+    xy_fb, st_fb, _ = O.lk_track(pp, pn, pts, win=WIN, max_level=MAX_LEVEL, flags=O.LK_USE_INITIAL_FLOW | O.LK_FORWARD_BACKWARD, fb_thresh=0.5)
+    out["lk_fb_status"] = st_fb
+    K4 = np.array([120.0, 118.0, 80.0, 56.0], dtype=np.float32)
+    imu_t = np.arange(0.0, 0.2, 0.005)
+    gyro = np.stack([0.3 * np.sin(7 * imu_t), 0.2 * np.cos(5 * imu_t), 0.5 + 0 * imu_t], axis=1)
+    R, used = O.integrate_gyro(imu_t, gyro, 0.05, 0.1, np.eye(3))
+    out["gyro_t"], out["gyro_w"], out["gyro_used"], out["gyro_R"] = imu_t, gyro, np.int32(used), R
+    out["gyro_K4"], out["gyro_H"] = K4, O.homography(K4, R)
+    out["gyro_pred"] = O.predict_flow(K4, R, pts)
+    return out
+
+
+if __name__ == "__main__":
+    data = build()
+    path = os.path.join(HERE, "frontend_golden.npz")
+    np.savez_compressed(path, **data)
+    print(path, os.path.getsize(path), "bytes;", int(data["lk_status"].sum()), "of", len(data["lk_status"]), "points tracked")
