@@ -69,17 +69,45 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// three wave-wide sums at once, stage by stage: the chains are independent, so the data-hazard wait states of one
+// DPP add are filled by the other two
+__device__ __forceinline__ void wave_sum3_i32(int& a, int& b, int& c) {
+#define LK_DPP_STAGE(ctrl, rmask)                                                     \
+    {                                                                                  \
+        const int ta = __builtin_amdgcn_update_dpp(0, a, ctrl, rmask, 0xF, false);     \
+        const int tb = __builtin_amdgcn_update_dpp(0, b, ctrl, rmask, 0xF, false);     \
+        const int tc = __builtin_amdgcn_update_dpp(0, c, ctrl, rmask, 0xF, false);     \
+        a += ta; b += tb; c += tc;                                                     \
+    }
+    LK_DPP_STAGE(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    LK_DPP_STAGE(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    LK_DPP_STAGE(0x141, 0xF)   // row_half_mirror
+    LK_DPP_STAGE(0x140, 0xF)   // row_mirror
+    LK_DPP_STAGE(0x142, 0xA)   // row_bcast15 into rows 1,3
+    LK_DPP_STAGE(0x143, 0xC)   // row_bcast31 into rows 2,3
+#undef LK_DPP_STAGE
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+    c = __builtin_amdgcn_readlane(c, 63);
+}
+
 // sums over the wave of two int32 values per lane with |v| < 2^30, exactly, as floats rounded once.  The low 10
 // bits of both travel in one register (two 16-bit fields: 64 * 1023 < 2^16), the high parts in one register each.
 __device__ __forceinline__ void wave_sum_exact2(int v1, int v2, float& s1, float& s2) {
-    const int lo = (v1 & 1023) | ((v2 & 1023) << 16);
-    const int slo = wave_sum_i32(lo), sh1 = wave_sum_i32(v1 >> 10), sh2 = wave_sum_i32(v2 >> 10);
+    int slo = (v1 & 1023) | ((v2 & 1023) << 16), sh1 = v1 >> 10, sh2 = v2 >> 10;
+    wave_sum3_i32(slo, sh1, sh2);
     s1 = (float)((double)sh1 * 1024.0 + (double)(slo & 0xffff));
     s2 = (float)((double)sh2 * 1024.0 + (double)((uint32_t)slo >> 16));
 }
-__device__ __forceinline__ float wave_sum_exact1(int v) {
-    const int slo = wave_sum_i32(v & 1023), sh = wave_sum_i32(v >> 10);
-    return (float)((double)sh * 1024.0 + (double)slo);
+// the same for three values: two registers of low parts, three of high parts
+__device__ __forceinline__ void wave_sum_exact3(int v1, int v2, int v3, float& s1, float& s2, float& s3) {
+    int slo = (v1 & 1023) | ((v2 & 1023) << 16), sh1 = v1 >> 10, sh2 = v2 >> 10;
+    int slo3 = v3 & 1023, sh3 = v3 >> 10, zero = 0;
+    wave_sum3_i32(slo, sh1, sh2);
+    wave_sum3_i32(slo3, sh3, zero);
+    s1 = (float)((double)sh1 * 1024.0 + (double)(slo & 0xffff));
+    s2 = (float)((double)sh2 * 1024.0 + (double)((uint32_t)slo >> 16));
+    s3 = (float)((double)sh3 * 1024.0 + (double)slo3);
 }
 
 struct BilinW { int w00, w01, w10, w11; };
@@ -390,19 +418,19 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             read_row_pairs_even<NP>(ilds, rc, boff, Ra);
             read_row_pairs_even<NP>(ilds, rc + 1, boff, Rb);
             read_row_pairs_even<NP>(ilds, rc + 2, boff, Rc);
-            read_row_pairs_even<NP>(ilds, rc + 3, boff, Rd);
             int sX[SEGLEN], sY[SEGLEN];
 #pragma unroll
             for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
             const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
-            if (inside) {
-                scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
-                scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
-            } else {
-                const int gy = ipy + rc;
-                scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, ipx + x0 - 1, w);
-                scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, ipx + x0 - 1, w);
-            }
+            const int gy = ipy + rc;
+            // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
+            if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
+            else scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, ipx + x0 - 1, w);
+            __builtin_amdgcn_sched_barrier(0);
+            read_row_pairs_even<NP>(ilds, rc + 3, boff, Rd);
+            if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
+            else scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, ipx + x0 - 1, w);
+            __builtin_amdgcn_sched_barrier(0);
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int m = 0; m < SEGLEN / 2; m++) {
@@ -420,8 +448,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 const int iw = dot2_acc(pc, wbot, dot2_acc(pb, wtop, 256)) >> 9;
                 Cw[k] = 256 - (iw << 9);
             }
-            wave_sum_exact2(a11, a22, A11, A22);
-            A12 = wave_sum_exact1(a12);
+            wave_sum_exact3(a11, a22, a12, A11, A22, A12);
             A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
         float D = A11 * A22 - A12 * A12;
