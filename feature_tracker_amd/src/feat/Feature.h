@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <array>
 #include <cstddef>
+#include <memory_resource>
 #include <unordered_map>
 #include <vector>
 
@@ -11,11 +12,22 @@ namespace feature_tracker {
 
 class Feature {
 public:
+    typedef std::pmr::vector<std::array<float, 2>> UvList;
+    typedef std::pmr::vector<double> TimeList;
+
+    // storage comes from `mem` (a feature database passes its own pool; the default is the global heap)
+    explicit Feature(std::pmr::memory_resource* mem = std::pmr::get_default_resource()) : uvs(mem), uvs_norm(mem), timestamps(mem) {}
+    Feature(const Feature& o, std::pmr::memory_resource* mem)
+        : featid(o.featid), to_delete(o.to_delete), uvs(o.uvs, mem), uvs_norm(o.uvs_norm, mem), timestamps(o.timestamps, mem),
+          anchor_cam_id(o.anchor_cam_id), anchor_clone_timestamp(o.anchor_clone_timestamp), p_FinA(o.p_FinA), p_FinG(o.p_FinG) {}
+    Feature(const Feature&) = delete;
+    Feature& operator=(const Feature&) = delete;
+
     size_t featid = 0;
     bool to_delete = false;
-    std::unordered_map<size_t, std::vector<std::array<float, 2>>> uvs;        // raw pixels per camera
-    std::unordered_map<size_t, std::vector<std::array<float, 2>>> uvs_norm;   // undistorted, normalized
-    std::unordered_map<size_t, std::vector<double>> timestamps;
+    std::pmr::unordered_map<size_t, UvList> uvs;        // raw pixels per camera
+    std::pmr::unordered_map<size_t, UvList> uvs_norm;   // undistorted, normalized
+    std::pmr::unordered_map<size_t, TimeList> timestamps;
     int anchor_cam_id = -1;
     double anchor_clone_timestamp = 0.0;
     std::array<double, 3> p_FinA{{0, 0, 0}};
@@ -34,6 +46,14 @@ public:
         hot_ts->push_back(timestamp);
     }
 
+    // pull the cache lines the next append(cam_id, ...) will write (no effect on the contents)
+    void prefetch_tail(size_t cam_id) const {
+        if (!hot_ts || hot_cam != cam_id) return;
+        __builtin_prefetch(hot_uv->data() + hot_uv->size(), 1);
+        __builtin_prefetch(hot_uvn->data() + hot_uvn->size(), 1);
+        __builtin_prefetch(hot_ts->data() + hot_ts->size(), 1);
+    }
+
     // keep only measurements taken at one of valid_times (src/feat/Feature.cpp:29-58)
     void clean_old_measurements(const std::vector<double>& valid_times) {
         filter([&](double t) { return std::find(valid_times.begin(), valid_times.end(), t) != valid_times.end(); });
@@ -50,9 +70,9 @@ public:
 
 private:
     size_t hot_cam = 0;
-    std::vector<std::array<float, 2>>* hot_uv = nullptr;
-    std::vector<std::array<float, 2>>* hot_uvn = nullptr;
-    std::vector<double>* hot_ts = nullptr;
+    UvList* hot_uv = nullptr;
+    UvList* hot_uvn = nullptr;
+    TimeList* hot_ts = nullptr;
 
     template <class Keep>
     void filter(Keep keep) {

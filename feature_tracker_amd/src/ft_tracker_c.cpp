@@ -95,7 +95,7 @@ struct ftk_group {
         long long tracked = 0, attempted = 0;
         int rc = FT_OK;
     };
-    static constexpr int MAIL_RING = 4;          // power of two
+    static constexpr int MAIL_RING = 4;          // power of two, >= PIPE_DEPTH + 2
     static constexpr int PIPE_DEPTH = 2;         // sets that may be in flight behind the one the caller collects
     Mail mail[MAIL_RING];
     std::thread driver;

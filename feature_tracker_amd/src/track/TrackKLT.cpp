@@ -132,34 +132,25 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
     } else if (plan.reset || !plan.run_lk) {
         pts.clear(); ids.clear();            // lost tracking: re-detect on the next frame (TrackKLT.cpp:118-129)
     } else {
-        std::vector<KeyPoint>& good = good_scratch;
-        std::vector<size_t>& good_ids = good_ids_scratch;
-        good.clear(); good_ids.clear();
-        good.reserve(pts.size()); good_ids.reserve(pts.size());
+        // keep the successfully tracked points, compacting in place, and note their raw pixel positions for the
+        // database; the undistortion of those positions happens in mono_commit, off the tracking path
+        const bool to_db = camera_k.count(plan.cam) != 0;    // TrackKLT.cpp:187-192
+        if (to_db) { plan.db_uvn.resize(4 * pts.size()); plan.db_ids.resize(pts.size()); }
+        size_t o = 0;
         for (size_t i = 0; i < pts.size(); i++) {
             const float x = plan.next_xy[2 * i], y = plan.next_xy[2 * i + 1];
             if (x < 0 || y < 0) continue;    // TrackKLT.cpp:138
             if (!plan.status[i]) continue;
-            KeyPoint kp = pts[i];
-            kp.pt = Point2f(x, y);
-            good.push_back(kp);
-            good_ids.push_back(ids[i]);
+            if (o != i) { pts[o] = pts[i]; ids[o] = ids[i]; }
+            pts[o].pt = Point2f(x, y);
+            if (to_db) { plan.db_uvn[4 * o] = x; plan.db_uvn[4 * o + 1] = y; plan.db_ids[o] = ids[o]; }
+            o++;
         }
-        const auto k_it = camera_k.find(plan.cam);
-        if (k_it != camera_k.end()) {            // TrackKLT.cpp:187-192: undistort now, write the database in mono_commit
-            const std::array<double, 4>& K = k_it->second;
-            const std::array<double, 4>& Dc = camera_d.at(plan.cam);
-            plan.db_uvn.resize(4 * good.size());
-            for (size_t i = 0; i < good.size(); i++) {
-                const Point2f npt = undistort_point_brown(good[i].pt, K, Dc);
-                plan.db_uvn[4 * i] = good[i].pt.x; plan.db_uvn[4 * i + 1] = good[i].pt.y;
-                plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
-            }
-            plan.db_ids = good_ids;
+        pts.resize(o); ids.resize(o);
+        if (to_db) {
+            plan.db_uvn.resize(4 * o); plan.db_ids.resize(o);
             plan.db_pending = true;
         }
-        pts.swap(good);
-        ids.swap(good_ids);
     }
     // keep the ranked detection of this frame for the next call
     cache_valid = cur_det.valid;
@@ -177,6 +168,13 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
 void TrackKLT::mono_commit(MonoPlan& plan) {
     if (!plan.db_pending) return;
     plan.db_pending = false;
+    // raw pixel -> normalized coordinates (TrackKLT.cpp:187-192); calibration is read-only while frames are fed
+    const std::array<double, 4>& K = camera_k.at(plan.cam);
+    const std::array<double, 4>& Dc = camera_d.at(plan.cam);
+    for (size_t i = 0; i < plan.db_ids.size(); i++) {
+        const Point2f npt = undistort_point_brown(Point2f(plan.db_uvn[4 * i], plan.db_uvn[4 * i + 1]), K, Dc);
+        plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
+    }
     database->update_features(plan.db_ids.size(), plan.db_ids.data(), plan.timestamp, plan.cam, plan.db_uvn.data());
 }
 

@@ -73,7 +73,7 @@ public:
         bool use_H = false;
         // observations of this frame waiting to be written to the feature database (see mono_commit)
         std::vector<size_t> db_ids;
-        std::vector<float> db_uvn;   // u, v, u_n, v_n per observation
+        std::vector<float> db_uvn;   // u, v, u_n, v_n per observation (u_n, v_n are filled in by mono_commit)
         bool db_pending = false;
     };
     // 1. choose the ring slot the new frame goes to (the caller ingests the frame into (plan.stream, plan.slot_cur))
@@ -185,8 +185,6 @@ protected:
     int slot_ring = 2;
     // per-tracker scratch reused every frame (no allocation in the steady state)
     Occupancy occ_scratch;
-    std::vector<KeyPoint> good_scratch;
-    std::vector<size_t> good_ids_scratch;
 
     // per camera: device slot holding the last pyramid (-1 = none), its size and timestamp
     struct CamState {

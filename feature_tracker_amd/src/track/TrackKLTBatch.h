@@ -66,7 +66,7 @@ public:
         }
         return true;
     }
-    // apply observations taken with take_db; touches only the feature databases, which carry their own locks, so it
+    // apply observations taken with take_db; reads the (fixed) calibration and writes the feature databases, which carry their own locks, so it
     // may run on another thread than begin()/complete() as long as one stream's sets are applied in order
     void commit_db(std::vector<TrackKLT::MonoPlan>& payload) {
         // serial on purpose: the worker pool belongs to the thread that runs begin()/complete()

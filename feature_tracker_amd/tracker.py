@@ -189,7 +189,7 @@ class BatchTracker(_Base):
         for i, f in enumerate(keep):
             self._ptrs[i] = f.ctypes.data
         # a pipelined set may complete up to three calls later: keep the arrays of the last four sets alive
-        self._keep = (getattr(self, "_keep", []) + [keep])[-4:]
+        self._keep = (getattr(self, "_keep", []) + [keep])[-6:]
         return self._feed(timestamps, 0, w, h, keep[0].strides[0], pipelined)
 
     def feed_device(self, timestamps, dev_ptrs, w, h, stride, pipelined=False):

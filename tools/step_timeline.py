@@ -26,11 +26,13 @@ for rep in range(3):
         t1 = time.perf_counter()
         b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
         dts.append(time.perf_counter() - t1)
+    t_loop = time.perf_counter() - t0
     b.flush()
     total = time.perf_counter() - t0
     d = np.array(dts) * 1e6
     st = b.stage_times()
-    print(f"rep {rep}: {1e6 * total / K:.0f} us/step; per-call p10 {np.percentile(d, 10):.0f} p50 {np.percentile(d, 50):.0f} p90 {np.percentile(d, 90):.0f} max {d.max():.0f}")
+    print(f"rep {rep}: loop {1e6 * t_loop / K:.0f} us/step, flush {1e3 * (total - t_loop):.2f} ms;", end=" ")
+    print(f"{1e6 * total / K:.0f} us/step; per-call p10 {np.percentile(d, 10):.0f} p50 {np.percentile(d, 50):.0f} p90 {np.percentile(d, 90):.0f} max {d.max():.0f}")
     print("   first 40:", " ".join(f"{x:.0f}" for x in d[:40]))
     print("   stages(us):", {k: round(v * 1e3) for k, v in st.items()})
     del b
