@@ -101,7 +101,9 @@ protected:
     // what cv::undistortPoints does for one point: remove K, then five fixed-point iterations of the inverse
     // radial-tangential model
     static Point2f undistort_point_brown(Point2f pt_in, const std::array<double, 4>& K, const std::array<double, 4>& D) {
-        const double x0 = ((double)pt_in.x - K[2]) / K[0], y0 = ((double)pt_in.y - K[3]) / K[1];
+        // cv::undistortPoints multiplies by the reciprocal focal lengths (ifx = 1./fx)
+        const double ifx = 1. / K[0], ify = 1. / K[1];
+        const double x0 = ((double)pt_in.x - K[2]) * ifx, y0 = ((double)pt_in.y - K[3]) * ify;
         double x = x0, y = y0;
         if (D[0] != 0. || D[1] != 0. || D[2] != 0. || D[3] != 0.) {
             for (int it = 0; it < 5; it++) {

@@ -171,9 +171,17 @@ void TrackKLT::mono_commit(MonoPlan& plan) {
     // raw pixel -> normalized coordinates (TrackKLT.cpp:187-192); calibration is read-only while frames are fed
     const std::array<double, 4>& K = camera_k.at(plan.cam);
     const std::array<double, 4>& Dc = camera_d.at(plan.cam);
-    for (size_t i = 0; i < plan.db_ids.size(); i++) {
-        const Point2f npt = undistort_point_brown(Point2f(plan.db_uvn[4 * i], plan.db_uvn[4 * i + 1]), K, Dc);
-        plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
+    if (Dc[0] == 0. && Dc[1] == 0. && Dc[2] == 0. && Dc[3] == 0.) {   // no distortion: the same arithmetic without the iteration
+        const double ifx = 1. / K[0], ify = 1. / K[1];
+        for (size_t i = 0; i < plan.db_ids.size(); i++) {
+            plan.db_uvn[4 * i + 2] = (float)(((double)plan.db_uvn[4 * i] - K[2]) * ifx);
+            plan.db_uvn[4 * i + 3] = (float)(((double)plan.db_uvn[4 * i + 1] - K[3]) * ify);
+        }
+    } else {
+        for (size_t i = 0; i < plan.db_ids.size(); i++) {
+            const Point2f npt = undistort_point_brown(Point2f(plan.db_uvn[4 * i], plan.db_uvn[4 * i + 1]), K, Dc);
+            plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
+        }
     }
     database->update_features(plan.db_ids.size(), plan.db_ids.data(), plan.timestamp, plan.cam, plan.db_uvn.data());
 }
