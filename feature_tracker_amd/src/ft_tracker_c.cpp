@@ -98,6 +98,7 @@ struct ftk_group {
     static constexpr int MAIL_RING = 4;          // power of two, >= PIPE_DEPTH + 2
     static constexpr int PIPE_DEPTH = 2;         // sets that may be in flight behind the one the caller collects
     Mail mail[MAIL_RING];
+    std::atomic<int> spin_us{20};   // how long a waiting side polls before it goes to sleep (microseconds)
     std::thread driver;
 
     // feature-database writer: nothing in tracking depends on the database, so its updates run on their own thread,
@@ -154,6 +155,8 @@ struct ftk_group {
             std::lock_guard<std::mutex> lk(wm);
             target = w_posted;
         }
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us.load(std::memory_order_relaxed));
+        while (w_done.load(std::memory_order_acquire) < target && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
         while (w_done.load(std::memory_order_acquire) < target) std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     std::mutex m;
@@ -189,7 +192,8 @@ struct ftk_group {
             const long next = done.load(std::memory_order_relaxed) + 1;
             // a short spin bridges back-to-back frames; after that sleep: a thread that spins for long steals issue
             // slots from whatever shares its core (the other group's driver, the HIP runtime's own threads)
-            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
+            // (a caller that feeds one set at a time and waits for it asks for a long spin: wake-ups would dominate its latency)
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us.load(std::memory_order_relaxed));
             while (posted.load(std::memory_order_acquire) < next && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
             if (posted.load(std::memory_order_acquire) < next) {
                 std::unique_lock<std::mutex> lk(m);
@@ -235,7 +239,7 @@ struct ftk_group {
     std::condition_variable dcv;
     std::atomic<int> waiters{0};
     Mail& wait(long seq) {
-        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us.load(std::memory_order_relaxed));
         while (done.load(std::memory_order_acquire) < seq && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
         if (done.load(std::memory_order_acquire) < seq) {
             std::unique_lock<std::mutex> lk(dm);
@@ -462,6 +466,7 @@ int ftk_batch_feed(ftk_batch* b, const double* timestamps, const void* const* fr
     if (rc != FT_OK) return rc;
     if ((rc = b->fill_frames(frames, frames_on_device, w, h, stride)) != FT_OK) return rc;
     tr = at = 0;
+    for (auto& g : b->groups) g->spin_us.store(1000, std::memory_order_relaxed);   // latency matters: poll, do not sleep
     b->post_all(timestamps);
     rc = b->collect(b->seq, tr, at);
     for (auto& g : b->groups) g->wait_db();    // the synchronous feed returns with the databases written
@@ -475,6 +480,7 @@ int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void*
     if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
     long long tr = 0, at = 0;
     const long depth = ftk_group::PIPE_DEPTH;
+    for (auto& g : b->groups) g->spin_us.store(20, std::memory_order_relaxed);     // throughput matters: leave the cores to the workers
     int rc = b->collect(b->seq - depth, tr, at);   // keeps the mailbox ring from wrapping onto a set still in use
     if (rc != FT_OK) return rc;
     if ((rc = b->fill_frames(frames, frames_on_device, w, h, stride)) != FT_OK) return rc;
