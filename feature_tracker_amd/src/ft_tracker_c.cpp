@@ -101,53 +101,65 @@ struct ftk_group {
     std::atomic<int> spin_us{20};   // how long a waiting side polls before it goes to sleep (microseconds)
     std::thread driver;
 
-    // feature-database writer: nothing in tracking depends on the database, so its updates run on their own thread,
-    // in frame order, off the driver's critical path
-    typedef std::vector<TrackKLT::MonoPlan> DbPayload;
-    std::thread writer;
+    // feature-database writers: nothing in tracking depends on the database, so its updates run on their own threads,
+    // off the driver's critical path.  Writer w applies the streams s with s % N_WRITERS == w of every frame set, in
+    // frame order, so one stream's observations are always applied in order by one thread.
+    static constexpr int N_WRITERS = 2;
+    struct DbJob {
+        std::vector<TrackKLT::MonoPlan> payload;
+        std::atomic<int> remaining{0};
+    };
+    std::thread writers[N_WRITERS];
     std::mutex wm;
     std::condition_variable wcv;
-    std::deque<std::unique_ptr<DbPayload>> wq, wfree;
+    std::deque<DbJob*> wq[N_WRITERS];
+    std::deque<std::unique_ptr<DbJob>> wfree;
+    std::vector<std::unique_ptr<DbJob>> wbusy;   // jobs in flight (owned here, referenced by the queues)
     long w_posted = 0;
     std::atomic<long> w_done{0};
     bool w_stop = false;
 
-    void writer_run() {
+    void writer_run(int w) {
         for (;;) {
-            std::unique_ptr<DbPayload> job;
+            DbJob* job;
             {
                 std::unique_lock<std::mutex> lk(wm);
-                wcv.wait(lk, [&] { return w_stop || !wq.empty(); });
-                if (wq.empty()) return;
-                job = std::move(wq.front());
-                wq.pop_front();
+                wcv.wait(lk, [&] { return w_stop || !wq[w].empty(); });
+                if (wq[w].empty()) return;
+                job = wq[w].front();
+                wq[w].pop_front();
             }
-            batch->commit_db(*job);
-            {
-                std::lock_guard<std::mutex> lk(wm);
-                wfree.push_back(std::move(job));
+            batch->commit_db(job->payload, w, N_WRITERS);
+            if (job->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // last writer of this set recycles it
+                {
+                    std::lock_guard<std::mutex> lk(wm);
+                    for (auto& b : wbusy)
+                        if (b.get() == job) { wfree.push_back(std::move(b)); std::swap(b, wbusy.back()); wbusy.pop_back(); break; }
+                }
+                w_done.fetch_add(1, std::memory_order_release);
             }
-            w_done.fetch_add(1, std::memory_order_release);
         }
     }
     void post_db() {
-        std::unique_ptr<DbPayload> job;
+        std::unique_ptr<DbJob> job;
         {
             std::lock_guard<std::mutex> lk(wm);
             if (!wfree.empty()) { job = std::move(wfree.front()); wfree.pop_front(); }
         }
-        if (!job) job.reset(new DbPayload());
-        if (!batch->take_db(*job)) {
+        if (!job) job.reset(new DbJob());
+        if (!batch->take_db(job->payload)) {
             std::lock_guard<std::mutex> lk(wm);
             wfree.push_back(std::move(job));
             return;
         }
+        job->remaining.store(N_WRITERS, std::memory_order_release);
         {
             std::lock_guard<std::mutex> lk(wm);
-            wq.push_back(std::move(job));
+            for (int w = 0; w < N_WRITERS; w++) wq[w].push_back(job.get());
+            wbusy.push_back(std::move(job));
             w_posted++;
         }
-        wcv.notify_one();
+        wcv.notify_all();
     }
     void wait_db() {
         long target;
@@ -166,7 +178,7 @@ struct ftk_group {
     bool stop = false;
 
     void start() {
-        writer = std::thread([this] { writer_run(); });
+        for (int w = 0; w < N_WRITERS; w++) writers[w] = std::thread([this, w] { writer_run(w); });
         driver = std::thread([this] { run(); });
     }
     void shutdown() {
@@ -178,14 +190,13 @@ struct ftk_group {
             cv.notify_all();
             driver.join();
         }
-        if (writer.joinable()) {
-            {
-                std::lock_guard<std::mutex> lk(wm);
-                w_stop = true;
-            }
-            wcv.notify_all();
-            writer.join();
+        {
+            std::lock_guard<std::mutex> lk(wm);
+            w_stop = true;
         }
+        wcv.notify_all();
+        for (auto& t : writers)
+            if (t.joinable()) t.join();
     }
     void run() {
         for (;;) {
