@@ -180,3 +180,17 @@ def test_pipelined_grouped_feed_equals_plain_feed():
         assert db == ref_db and tracks == ref_tracks      # deferred database writes all land
         for (xy_a, id_a), (xy_b, id_b) in zip(pts, ref_pts):
             assert np.array_equal(id_a, id_b) and np.array_equal(xy_a, xy_b)
+
+
+def test_feature_database_cpp(tmp_path):
+    """Compiles and runs tests/cpp/test_feature_db.cpp against the host sources (no GPU, no device library)."""
+    import subprocess
+    exe = str(tmp_path / "test_feature_db")
+    src = os.path.join(ROOT, "tests", "cpp", "test_feature_db.cpp")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(ROOT, "feature_tracker_amd", "src"), "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-pthread"])
+    # the harness preloads a library of its own: the sanitizer runtime must tolerate not being first
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1")
+    res = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "checks passed" in res.stdout

@@ -1,3 +1,4 @@
+"""Host bookkeeping scaling over stream groups and helper threads on the CPU checker backend (no GPU needed)."""
 import sys, time, ctypes, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
