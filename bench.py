@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per GPU (0 = library default)")
     ap.add_argument("--host-frames", action="store_true",
                     help="feed frames from host memory (PCIe-inclusive rate; not the headline configuration)")
+    ap.add_argument("--reject-outliers", action="store_true",
+                    help="also run the fundamental-matrix outlier rejection after LK (not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -158,6 +160,8 @@ def main():
     from feature_tracker_amd import tracker
 
     wl = WORKLOADS[args.workload]
+    if args.reject_outliers:
+        wl = dict(wl, opts=dict(wl["opts"], reject_outliers=1), desc=wl["desc"] + " + outlier rejection")
     K, W = args.steps, args.warmup
     n_frames = W + K + 1                       # + the first frame, which only detects
     threads = min(16, os.cpu_count() or 8)

@@ -17,6 +17,7 @@
 #include "ft_common.hpp"
 #include "ft_kernels_fast.hpp"
 #include "ft_kernels_lk.hpp"
+#include "ft_kernels_outlier.hpp"
 #include "ft_kernels_pyramid.hpp"
 
 using namespace ftd;
@@ -79,6 +80,8 @@ struct ft_ctx {
     uint8_t* lk_in_host_dev = nullptr;    // device-side address of lk_in_host
     uint8_t* lk_out_host = nullptr; uint8_t* lk_out_dev = nullptr; size_t lk_out_bytes = 0;
     uint8_t* lk_out_host_dev = nullptr;   // device-side address of lk_out_host
+    float4* lk_norm_dev = nullptr;        // outlier rejection: normalized point pairs
+    double* ransac_sys_dev = nullptr;     // outlier rejection: 8x9 systems, allocated on first use
     PendingLK lk_pending;
 
     // FAST scratch
@@ -202,8 +205,8 @@ int deliver_pending(ft_ctx* c, uint64_t upto) {
         for (const ft_lk_job& j : P.jobs) {
             const size_t n = (size_t)j.n;
             if (n) {
-                memcpy(j.next_xy, xy + 2 * off, 8 * n);
-                memcpy(j.err, er + off, 4 * n);
+                if (j.next_xy) memcpy(j.next_xy, xy + 2 * off, 8 * n);   // absent for a rejection-only batch
+                if (j.err) memcpy(j.err, er + off, 4 * n);
                 memcpy(j.status, st + off, n);
                 if (j.iters && P.want_iters) memcpy(j.iters, it + off * P.nlev, sizeof(int) * n * P.nlev);
             }
@@ -368,6 +371,8 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     }
     if (hipMalloc(&p, c->lk_out_bytes) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_out_dev = (uint8_t*)p;
+    if (hipMalloc(&p, sizeof(float4) * N) != hipSuccess) return fail(FT_E_NOMEM);
+    c->lk_norm_dev = (float4*)p;
 
     // FAST scratch
     c->cand_entries_per_img = ((size_t)lim->max_width + 2 * 64) * ((size_t)lim->max_height + 2 * 64) / 4 + (size_t)lim->max_grid_cells;
@@ -415,6 +420,8 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_in_dev) (void)hipFree(c->lk_in_dev);
     if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
+    if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
+    if (c->ransac_sys_dev) (void)hipFree(c->ransac_sys_dev);
     if (c->cand) (void)hipFree(c->cand);
     if (c->cand_count) (void)hipFree(c->cand_count);
     for (auto& h : c->fast_out_host) if (h) (void)hipHostFree(h);
@@ -553,6 +560,8 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     const int seglen = pick_seglen(prm->win_w, prm->win_h);
     if (!seglen) return FT_E_INVALID;
     const bool fb = (prm->flags & FT_LK_FORWARD_BACKWARD) != 0;
+    const bool reject = (prm->flags & FT_LK_REJECT_OUTLIERS) != 0;
+    if (reject && (prm->ransac_hypotheses < 0 || prm->ransac_hypotheses > 256)) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
     if (c->lk_pending.active) {   // staging is single-buffered: finish the previous batch first
         int rc = sync_and_deliver(c);
@@ -565,6 +574,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         const ft_lk_job& J = jobs[j];
         if (J.n < 0) return FT_E_INVALID;
         if (J.n > 0 && (!J.prev_xy || !J.next_xy || !J.status || !J.err)) return FT_E_INVALID;
+        if (reject && J.n > 0 && (!J.calib_prev || !J.calib_next)) return FT_E_INVALID;
         total += (size_t)J.n;
         if (J.iters) want_iters = true;
     }
@@ -598,6 +608,9 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         dj[j].img_prev = sp; dj[j].img_next = sn; dj[j].w0 = P.w; dj[j].h0 = P.h;
         dj[j].use_H = J.H ? 1 : 0;
         if (J.H) memcpy(dj[j].H, J.H, sizeof(float) * 9); else memset(dj[j].H, 0, sizeof(float) * 9);
+        dj[j].first = (int)off; dj[j].count = J.n;
+        if (reject && J.n > 0) { memcpy(dj[j].calib, J.calib_prev, sizeof(double) * 8); memcpy(dj[j].calib + 8, J.calib_next, sizeof(double) * 8); }
+        else memset(dj[j].calib, 0, sizeof(dj[j].calib));
         for (int i = 0; i < J.n; i++) ptjob[off + i] = (uint16_t)j;
         if (J.n) {
             memcpy(pxy + 2 * off, J.prev_xy, 8 * (size_t)J.n);
@@ -622,7 +635,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.guess_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_next);
     // Without a backward pass (which reads the forward results on the device) and without iteration counters, lane 0
     // of every wave writes its 13 result bytes straight into the pinned host block: no copy command to enqueue.
-    const bool direct_out = !fb && !want_iters;
+    const bool direct_out = !fb && !want_iters && !reject;
     uint8_t* ob = direct_out ? c->lk_out_host_dev : c->lk_out_dev;
     a.next_xy = reinterpret_cast<float*>(ob);
     a.err = reinterpret_cast<float*>(ob + 8 * N);
@@ -656,7 +669,27 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
 
-    if (!direct_out) {
+    if (reject) {
+        // final mask on the device; the kernel also moves positions, residuals and status into the pinned host block
+        if (!c->ransac_sys_dev) {
+            void* p = nullptr;
+            FT_HIP(c, hipMalloc(&p, sizeof(double) * 72 * 256 * FT_MAX_BATCH));
+            c->ransac_sys_dev = (double*)p;
+        }
+        OutlierArgs o;
+        o.jobs = a.jobs;
+        o.prev_xy = a.prev_xy; o.next_xy = a.next_xy; o.err = a.err; o.status = a.status;
+        o.norm = c->lk_norm_dev;
+        o.out_xy = reinterpret_cast<float*>(c->lk_out_host_dev);
+        o.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);
+        o.out_status = c->lk_out_host_dev + 12 * N;
+        o.hypotheses = prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 256;
+        o.seed = prm->ransac_seed;
+        hipLaunchKernelGGL(reject_outliers_kernel, dim3(n_jobs), dim3(256), 0, c->q, o, c->ransac_sys_dev);
+        FT_HIP(c, hipGetLastError());
+        if (want_iters)
+            FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
+    } else if (!direct_out) {
         const size_t out_bytes = align_up(13 * N, 16) + (want_iters ? sizeof(int) * N * nlev : 0);
         FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, c->q));
     }
@@ -666,6 +699,79 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.count_work = c->profile; P.active = true;
     P.seq = ++c->seq;
     return FT_OK;
+}
+
+int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed) {
+    if (!c || !sets || n_sets < 1 || n_sets > FT_MAX_BATCH || hypotheses < 0 || hypotheses > 256) return FT_E_INVALID;
+    size_t N = 0;
+    for (int j = 0; j < n_sets; j++) {
+        const ft_match_set& S = sets[j];
+        if (S.n < 0 || (S.n > 0 && (!S.prev_xy || !S.next_xy || !S.status || !S.calib_prev || !S.calib_next))) return FT_E_INVALID;
+        N += (size_t)S.n;
+    }
+    if (N > (size_t)c->lim.max_points) return FT_E_LIMIT;
+    if (N == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    if (c->lk_pending.active) {   // the tracking batches' staging blocks are reused
+        int rc = sync_and_deliver(c);
+        if (rc) return rc;
+    }
+    // same input block as a tracking batch; the per-point job index is not needed here, its place holds the status bytes
+    uint8_t* hb = c->lk_in_host;
+    const size_t off_status = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256);
+    const size_t off_prev = off_status + align_up(2 * (size_t)c->lim.max_points, 256);
+    const size_t off_next = off_prev + align_up(8 * (size_t)c->lim.max_points, 256);
+    LKJobDev* dj = reinterpret_cast<LKJobDev*>(hb);
+    std::vector<ft_lk_job> deliver((size_t)n_sets);
+    size_t off = 0;
+    for (int j = 0; j < n_sets; j++) {
+        const ft_match_set& S = sets[j];
+        memset(&dj[j], 0, sizeof(LKJobDev));
+        dj[j].first = (int)off; dj[j].count = S.n;
+        memset(&deliver[j], 0, sizeof(ft_lk_job));
+        deliver[j].n = S.n; deliver[j].status = S.status;
+        if (S.n) {
+            memcpy(dj[j].calib, S.calib_prev, sizeof(double) * 8);
+            memcpy(dj[j].calib + 8, S.calib_next, sizeof(double) * 8);
+            memcpy(hb + off_status + off, S.status, (size_t)S.n);
+            memcpy(hb + off_prev + 8 * off, S.prev_xy, 8 * (size_t)S.n);
+            memcpy(hb + off_next + 8 * off, S.next_xy, 8 * (size_t)S.n);
+        }
+        off += (size_t)S.n;
+    }
+    const int n16 = (int)((off_next + 8 * N + 15) / 16);
+    hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->q, reinterpret_cast<const uint4*>(c->lk_in_host_dev),
+                       reinterpret_cast<uint4*>(c->lk_in_dev), n16);
+    if (!c->ransac_sys_dev) {
+        void* p = nullptr;
+        FT_HIP(c, hipMalloc(&p, sizeof(double) * 72 * 256 * FT_MAX_BATCH));
+        c->ransac_sys_dev = (double*)p;
+    }
+    OutlierArgs o;
+    o.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
+    o.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);
+    o.next_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_next);
+    o.err = reinterpret_cast<const float*>(c->lk_out_dev + 8 * N);   // passed through by the kernel, not delivered
+    o.status = c->lk_in_dev + off_status;
+    o.norm = c->lk_norm_dev;
+    o.out_xy = reinterpret_cast<float*>(c->lk_out_host_dev);
+    o.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);
+    o.out_status = c->lk_out_host_dev + 12 * N;
+    o.hypotheses = hypotheses > 0 ? hypotheses : 256;
+    o.seed = seed;
+    hipLaunchKernelGGL(reject_outliers_kernel, dim3(n_sets), dim3(256), 0, c->q, o, c->ransac_sys_dev);
+    FT_HIP(c, hipGetLastError());
+    PendingLK& P = c->lk_pending;
+    P.jobs = std::move(deliver);
+    P.total = (int)N; P.nlev = 0; P.want_iters = false; P.count_work = false; P.active = true;
+    P.seq = ++c->seq;
+    return FT_OK;
+}
+
+int ft_reject_outliers(ft_ctx* c, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed) {
+    int rc = ft_reject_outliers_async(c, n_sets, sets, hypotheses, seed);
+    if (rc) return rc;
+    return ft_sync(c);
 }
 
 int ft_lk_track(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) {

@@ -27,6 +27,8 @@ struct LKJobDev {
     int w0, h0;               // level-0 size (both images)
     int use_H;                // 1: initial guess = pi(H * [prev;1])
     float H[9];
+    int first, count;         // this job's points in the batch arrays
+    double calib[16];         // fx fy cx cy k1 k2 p1 p2 of the template camera, then of the target camera (outlier rejection)
 };
 
 struct LKArgs {

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libft_device.so")
 FT_LK_USE_INITIAL_FLOW = 4
 FT_LK_GET_MIN_EIGENVALS = 8
 FT_LK_FORWARD_BACKWARD = 256
+FT_LK_REJECT_OUTLIERS = 512
 FT_MAX_LEVELS = 8
 FT_MAX_WIN = 32
 FT_MAX_BATCH = 256
@@ -32,13 +33,19 @@ class ft_limits(C.Structure):
 
 class ft_lk_params(C.Structure):
     _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("max_iter", C.c_int),
-                ("eps", C.c_double), ("min_eig", C.c_double), ("flags", C.c_int), ("fb_thresh", C.c_float)]
+                ("eps", C.c_double), ("min_eig", C.c_double), ("flags", C.c_int), ("fb_thresh", C.c_float),
+                ("ransac_hypotheses", C.c_int), ("ransac_seed", C.c_uint)]
 
 
 class ft_lk_job(C.Structure):
     _fields_ = [("stream_prev", C.c_int), ("slot_prev", C.c_int), ("stream_next", C.c_int), ("slot_next", C.c_int),
                 ("n", C.c_int), ("prev_xy", C.c_void_p), ("next_xy", C.c_void_p), ("status", C.c_void_p),
-                ("err", C.c_void_p), ("H", C.c_void_p), ("iters", C.c_void_p)]
+                ("err", C.c_void_p), ("H", C.c_void_p), ("iters", C.c_void_p), ("calib_prev", C.c_void_p), ("calib_next", C.c_void_p)]
+
+
+class ft_match_set(C.Structure):
+    _fields_ = [("n", C.c_int), ("prev_xy", C.c_void_p), ("next_xy", C.c_void_p), ("status", C.c_void_p),
+                ("calib_prev", C.c_void_p), ("calib_next", C.c_void_p)]
 
 
 class ft_keypoint(C.Structure):
@@ -54,7 +61,7 @@ class ft_kernel_time(C.Structure):
 # every symbol include/ft_device.h declares
 SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device",
            "ft_set_frames_device_pyramid", "ft_build_pyramid",
-           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_fast_grid", "ft_fast_grid_async",
+           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_fast_grid", "ft_fast_grid_async",
            "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
            "ft_last_hip_error", "ft_device_count"]
@@ -100,6 +107,8 @@ def load_library():
     lib.ft_build_gradients.argtypes = [vp, C.c_int, ip, ip]
     lib.ft_lk_track.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
     lib.ft_lk_track_async.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
+    lib.ft_reject_outliers.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
+    lib.ft_reject_outliers_async.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
     fg = [vp, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ft_keypoint), C.c_int, ip, ip]
     lib.ft_fast_grid.argtypes = fg
     lib.ft_fast_grid_async.argtypes = fg
@@ -139,13 +148,16 @@ class LKParams:
     """Window, depth and termination of one calcOpticalFlowPyrLK call (defaults: src/track/TrackKLT.h:121-122,
     src/track/TrackKLT.cpp:305,:401)."""
 
-    def __init__(self, win=15, max_level=3, max_iter=15, eps=0.01, min_eig=1e-4, flags=FT_LK_USE_INITIAL_FLOW, fb_thresh=1.0):
+    def __init__(self, win=15, max_level=3, max_iter=15, eps=0.01, min_eig=1e-4, flags=FT_LK_USE_INITIAL_FLOW, fb_thresh=1.0,
+                 ransac_hypotheses=0, ransac_seed=0):
         self.win_w, self.win_h = (win, win) if np.isscalar(win) else win
         self.max_level, self.max_iter, self.eps, self.min_eig = max_level, max_iter, eps, min_eig
         self.flags, self.fb_thresh = flags, fb_thresh
+        self.ransac_hypotheses, self.ransac_seed = ransac_hypotheses, ransac_seed
 
     def c_struct(self):
-        return ft_lk_params(self.win_w, self.win_h, self.max_level, self.max_iter, self.eps, self.min_eig, self.flags, self.fb_thresh)
+        return ft_lk_params(self.win_w, self.win_h, self.max_level, self.max_iter, self.eps, self.min_eig, self.flags, self.fb_thresh,
+                            self.ransac_hypotheses, self.ransac_seed)
 
 
 class DeviceContext:
@@ -262,16 +274,37 @@ class DeviceContext:
             er = np.zeros(n, dtype=np.float32)
             it = np.full((n, nlev), -1, dtype=np.int32) if want_iters else None
             H = None if j.get("H") is None else np.ascontiguousarray(j["H"], dtype=np.float32).reshape(9)
+            c0 = None if j.get("calib_prev") is None else np.ascontiguousarray(j["calib_prev"], dtype=np.float64).reshape(8)
+            c1 = c0 if j.get("calib_next") is None else np.ascontiguousarray(j["calib_next"], dtype=np.float64).reshape(8)
             cj[i] = ft_lk_job(j["prev"][0], j["prev"][1], j["next"][0], j["next"][1], n, prev_xy.ctypes.data, nxt.ctypes.data,
                               st.ctypes.data, er.ctypes.data, None if H is None else H.ctypes.data,
-                              None if it is None else it.ctypes.data)
-            keep += [prev_xy, nxt, st, er, it, H]
+                              None if it is None else it.ctypes.data, None if c0 is None else c0.ctypes.data,
+                              None if c1 is None else c1.ctypes.data)
+            keep += [prev_xy, nxt, st, er, it, H, c0, c1]
             outs.append((nxt, st, er, it) if want_iters else (nxt, st, er))
         p = params.c_struct()
         fn = self.lib.ft_lk_track if sync else self.lib.ft_lk_track_async
         self._check(fn(self._ctx, len(jobs), cj, C.byref(p)), "ft_lk_track")
         if not sync:
             self._keep += keep + [cj]
+        return outs
+
+    def reject_outliers(self, sets, hypotheses=256, seed=0):
+        """sets: list of dicts {prev_xy:(n,2), next_xy:(n,2), status:(n,) uint8 | None, calib_prev:(8,), calib_next:(8,) | None}.
+        Returns the list of output status arrays."""
+        cs = (ft_match_set * len(sets))()
+        keep, outs = [], []
+        for i, q in enumerate(sets):
+            a = np.ascontiguousarray(q["prev_xy"], dtype=np.float32).reshape(-1, 2)
+            b = np.ascontiguousarray(q["next_xy"], dtype=np.float32).reshape(-1, 2)
+            n = a.shape[0]
+            st = np.ones(n, dtype=np.uint8) if q.get("status") is None else np.array(q["status"], dtype=np.uint8).copy()
+            c0 = np.ascontiguousarray(q["calib_prev"], dtype=np.float64).reshape(8)
+            c1 = c0 if q.get("calib_next") is None else np.ascontiguousarray(q["calib_next"], dtype=np.float64).reshape(8)
+            cs[i] = ft_match_set(n, a.ctypes.data, b.ctypes.data, st.ctypes.data, c0.ctypes.data, c1.ctypes.data)
+            keep += [a, b, c0, c1]
+            outs.append(st)
+        self._check(self.lib.ft_reject_outliers(self._ctx, len(sets), cs, hypotheses, seed), "ft_reject_outliers")
         return outs
 
     # -- FAST --

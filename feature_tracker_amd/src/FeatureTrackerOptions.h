@@ -32,6 +32,10 @@ struct FeatureTrackerOptions {
     bool forward_backward = false;
     float fb_thresh = 1.0f;     // px
     bool speculative_detect = true;   // run the detector on every new frame so replenishment needs no extra sync
+    // outlier rejection after LK (the reference always does it, src/track/TrackKLT.cpp:405-424; here it is a switch
+    // because the sampling is this build's own and cannot reproduce OpenCV's inlier sets)
+    bool reject_outliers = false;
+    int ransac_hypotheses = 256;
 
     void print_trackers() const {
         printf("FEATURE TRACKING PARAMETERS:\n");

@@ -31,6 +31,7 @@ FeatureTrackerOptions to_options(const ftk_options& o) {
     r.min_px_dist = o.min_px_dist; r.pyr_levels = o.pyr_levels; r.win_size = o.win_size; r.lk_max_iter = o.lk_max_iter;
     r.lk_eps = o.lk_eps; r.lk_min_eig = o.lk_min_eig; r.use_gyro_seed = o.use_gyro_seed != 0;
     r.forward_backward = o.forward_backward != 0; r.fb_thresh = o.fb_thresh; r.speculative_detect = o.speculative_detect != 0;
+    r.reject_outliers = o.reject_outliers != 0; if (o.ransac_hypotheses > 0) r.ransac_hypotheses = o.ransac_hypotheses;
     return r;
 }
 
@@ -321,6 +322,7 @@ void ftk_default_options(ftk_options* o) {
     o->min_px_dist = d.min_px_dist; o->pyr_levels = d.pyr_levels; o->win_size = d.win_size; o->lk_max_iter = d.lk_max_iter;
     o->lk_eps = d.lk_eps; o->lk_min_eig = d.lk_min_eig; o->use_gyro_seed = d.use_gyro_seed; o->forward_backward = d.forward_backward;
     o->fb_thresh = d.fb_thresh; o->speculative_detect = d.speculative_detect;
+    o->reject_outliers = d.reject_outliers; o->ransac_hypotheses = d.ransac_hypotheses;
 }
 
 const char* ftk_backend_name(void) { return ftk_backend_label(); }

@@ -15,8 +15,10 @@ ft_lk_params TrackKLT::lk_params() const {
     p.max_iter = lk_max_iter;                // TermCriteria(COUNT + EPS, 15, 0.01), TrackKLT.cpp:305,:401
     p.eps = lk_eps;
     p.min_eig = lk_min_eig;
-    p.flags = FT_LK_USE_INITIAL_FLOW | (forward_backward ? FT_LK_FORWARD_BACKWARD : 0);
+    p.flags = FT_LK_USE_INITIAL_FLOW | (forward_backward ? FT_LK_FORWARD_BACKWARD : 0) | (reject_outliers ? FT_LK_REJECT_OUTLIERS : 0);
     p.fb_thresh = fb_thresh;
+    p.ransac_hypotheses = ransac_hypotheses;     // TrackKLT.cpp:405-424
+    p.ransac_seed = frames_fed;
     return p;
 }
 
@@ -28,6 +30,16 @@ void TrackKLT::filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, s
         o++;
     }
     pts.resize(o); ids.resize(o);
+}
+
+void TrackKLT::calib8_of(size_t cam_id, double* out8) const {
+    const auto k = camera_k.find(cam_id);
+    const auto d = camera_d.find(cam_id);
+    const double ident[4] = {1., 1., 0., 0.};
+    for (int i = 0; i < 4; i++) {
+        out8[i] = k != camera_k.end() ? k->second[i] : ident[i];
+        out8[4 + i] = d != camera_d.end() ? d->second[i] : 0.;
+    }
 }
 
 bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float* H) {
@@ -51,6 +63,7 @@ void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, M
     plan.first = plan.run_lk = plan.reset = plan.use_H = plan.db_pending = false;
     plan.prev_xy.clear(); plan.next_xy.clear(); plan.err.clear(); plan.status.clear(); plan.db_ids.clear(); plan.db_uvn.clear();
     plan.cam = cam_id;
+    frames_fed++;
     plan.timestamp = timestamp;
     plan.stream = stream0 + (int)cam_id;
     plan.slot_last = cs.slot_last;
@@ -120,6 +133,10 @@ void TrackKLT::mono_prepare(MonoPlan& plan, const Detection& last_det, ft_lk_job
     job.status = plan.status.data(); job.err = plan.err.data();
     job.H = plan.use_H ? plan.H : nullptr;
     job.iters = nullptr;
+    if (reject_outliers) {
+        calib8_of(plan.cam, plan.calib8);
+        job.calib_prev = plan.calib8; job.calib_next = plan.calib8;
+    }
 }
 
 void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
@@ -243,7 +260,7 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
 
 void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
     const ft_lk_params prm = lk_params();
-    struct Buf { std::vector<float> p0, p1, err; std::vector<uint8_t> st; };
+    struct Buf { std::vector<float> p0, p1, err; std::vector<uint8_t> st; double c0[8], c1[8]; };
     std::vector<Buf> bufs(jobs.size());
     std::vector<ft_lk_job> lk;
     std::vector<size_t> lk_owner;
@@ -265,6 +282,10 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
         J.stream_next = M.img1.stream; J.slot_next = M.img1.slot;
         J.n = (int)n; J.prev_xy = B.p0.data(); J.next_xy = B.p1.data(); J.status = B.st.data(); J.err = B.err.data();
         J.H = M.H;
+        if (reject_outliers) {
+            calib8_of(M.id0, B.c0); calib8_of(M.id1, B.c1);
+            J.calib_prev = B.c0; J.calib_next = B.c1;
+        }
         lk.push_back(J);
         lk_owner.push_back(j);
     }
@@ -274,7 +295,8 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
         MatchJob& M = jobs[lk_owner[q]];
         Buf& B = bufs[lk_owner[q]];
         const size_t n = M.kpts0->size();
-        // outlier rejection by fundamental-matrix RANSAC (TrackKLT.cpp:405-424) is not part of this build: LK status only
+        // with reject_outliers the status already carries the RANSAC verdict (TrackKLT.cpp:405-424 -> the device's
+        // rejection kernel); otherwise it is the LK status alone
         M.mask_out->assign(B.st.begin(), B.st.end());
         for (size_t i = 0; i < n; i++) (*M.kpts1)[i].pt = Point2f(B.p1[2 * i], B.p1[2 * i + 1]);   // TrackKLT.cpp:427-430
     }

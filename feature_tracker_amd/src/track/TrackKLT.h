@@ -51,7 +51,8 @@ public:
         : TrackBase(o.num_pts, numaruco), be(backend), stream0(stream_base), threshold(o.fast_threshold), grid_x(o.grid_x),
           grid_y(o.grid_y), min_px_dist(o.min_px_dist), pyr_levels(o.pyr_levels), win_size(o.win_size), lk_max_iter(o.lk_max_iter),
           lk_eps(o.lk_eps), lk_min_eig(o.lk_min_eig), use_gyro_seed(o.use_gyro_seed), forward_backward(o.forward_backward),
-          fb_thresh(o.fb_thresh), speculative_detect(o.speculative_detect) {}
+          fb_thresh(o.fb_thresh), speculative_detect(o.speculative_detect), reject_outliers(o.reject_outliers),
+          ransac_hypotheses(o.ransac_hypotheses) {}
 
     void feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) override;
 
@@ -71,6 +72,7 @@ public:
         std::vector<uint8_t> status;
         float H[9];
         bool use_H = false;
+        double calib8[8];          // camera model handed to the outlier rejection
         // observations of this frame waiting to be written to the feature database (see mono_commit)
         std::vector<size_t> db_ids;
         std::vector<float> db_uvn;   // u, v, u_n, v_n per observation (u_n, v_n are filled in by mono_commit)
@@ -162,6 +164,8 @@ protected:
     };
     static void filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, std::vector<size_t>& ids);
     bool gyro_homography(size_t cam_id, double t_last, double t_cur, float* H);
+    // fx fy cx cy k1 k2 p1 p2 of a camera; an uncalibrated camera counts as the identity model
+    void calib8_of(size_t cam_id, double* out8) const;
 
     FrontendBackend* be;
     int stream0;
@@ -182,6 +186,9 @@ protected:
     bool forward_backward = false;
     float fb_thresh = 1.0f;
     bool speculative_detect = true;
+    bool reject_outliers = false;
+    int ransac_hypotheses = 256;
+    unsigned frames_fed = 0;   // seeds the outlier rejection's sample sequence: every frame draws other samples
     int slot_ring = 2;
     // per-tracker scratch reused every frame (no allocation in the steady state)
     Occupancy occ_scratch;

@@ -44,6 +44,12 @@ extern "C" {
 #define FT_LK_USE_INITIAL_FLOW 4
 #define FT_LK_GET_MIN_EIGENVALS 8
 #define FT_LK_FORWARD_BACKWARD 256
+/* After tracking, reject outliers per job with a RANSAC on the fundamental matrix of the undistorted point pairs:
+ * the tail of TrackKLT::perform_matching, src/track/TrackKLT.cpp:405-424 (undistort_point + cv::findFundamentalMat
+ * (FM_RANSAC, 1/max_focal, 0.999) + mask_klt & mask_ransac).  Model, error measure and threshold are OpenCV's; the
+ * sampling is this library's own seeded scheme, because OpenCV's random sequence cannot be reproduced without it.
+ * Jobs need calib_prev / calib_next. */
+#define FT_LK_REJECT_OUTLIERS 512
 
 typedef struct ft_ctx ft_ctx;
 
@@ -65,6 +71,8 @@ typedef struct ft_lk_params {
     double min_eig;      /* OpenCV default 1e-4 */
     int flags;           /* FT_LK_* */
     float fb_thresh;     /* px; only with FT_LK_FORWARD_BACKWARD */
+    int ransac_hypotheses;    /* only with FT_LK_REJECT_OUTLIERS: models tried per job, 1..256 (0 = 256) */
+    unsigned ransac_seed;     /* only with FT_LK_REJECT_OUTLIERS: seed of the sample sequence */
 } ft_lk_params;
 
 /* One LK job = one calcOpticalFlowPyrLK call of the reference (one image pair, n points). */
@@ -78,7 +86,19 @@ typedef struct ft_lk_job {
     float* err;                   /* n */
     const float* H;               /* optional row-major 3x3: the initial guess becomes pi(H*[prev;1]) (gyro seed) */
     int* iters;                   /* optional n*(max_level+1): Newton iterations per level, -1 = level skipped */
+    const double* calib_prev;     /* with FT_LK_REJECT_OUTLIERS: fx fy cx cy k1 k2 p1 p2 of the template image's camera */
+    const double* calib_next;     /* ... and of the target image's camera (the same pointer for temporal tracking) */
 } ft_lk_job;
+
+/* One set of point correspondences for outlier rejection alone. */
+typedef struct ft_match_set {
+    int n;
+    const float* prev_xy;         /* n*2 pixels in the first image */
+    const float* next_xy;         /* n*2 pixels in the second image */
+    uint8_t* status;              /* n, in: 1 = still a candidate, out: candidate AND inlier of the winning model */
+    const double* calib_prev;     /* fx fy cx cy k1 k2 p1 p2 of the first image's camera */
+    const double* calib_next;     /* ... of the second image's camera */
+} ft_match_set;
 
 typedef struct ft_keypoint {
     float x, y;          /* full-image pixel position */
@@ -125,6 +145,15 @@ int ft_build_gradients(ft_ctx* ctx, int n, const int* streams, const int* slots)
  * ft_lk_track_async returns after enqueueing and the outputs are written by the next ft_sync. */
 int ft_lk_track(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm);
 int ft_lk_track_async(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm);
+
+/* Outlier rejection on correspondences the caller already holds: undistort_point + cv::findFundamentalMat(FM_RANSAC,
+ * 1/max_focal, 0.999) + "mask_klt && mask_ransac" of src/track/TrackKLT.cpp:405-424, for n_sets point sets in one
+ * launch (all n points of a set enter the estimation, as in the reference; status only gates the output).  Same model
+ * search as FT_LK_REJECT_OUTLIERS.  Fewer than 8 points, or no model with at least 8 inliers, clears the whole set.
+ * hypotheses 1..256 (0 = 256).  Shares its staging with ft_lk_track: total points <= limits.max_points, and an
+ * undelivered tracking batch is finished first. */
+int ft_reject_outliers(ft_ctx* ctx, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed);
+int ft_reject_outliers_async(ft_ctx* ctx, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed);
 
 /* Per-cell FAST-9/16 + 3x3 NMS + per-cell top `per_cell` by (response desc, y asc, x asc), for n images.
  * Image i writes at most `cap` keypoints at out + i*cap, cells in index order, and its count to n_out[i].

@@ -31,6 +31,8 @@ typedef struct ftk_options {
     int forward_backward;
     float fb_thresh;
     int speculative_detect;
+    int reject_outliers;    /* RANSAC on the fundamental matrix after LK, src/track/TrackKLT.cpp:405-424 -> off (see FT_LK_REJECT_OUTLIERS) */
+    int ransac_hypotheses;  /* -> 256 */
 } ftk_options;
 
 typedef struct ftk_tracker ftk_tracker;

@@ -637,4 +637,137 @@ void fto_predict_flow(const float* K4, const float* R_p_c, const float* xy, floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// outlier rejection (see ft_oracle.h)
+// ---------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+// what TrackBase::undistort_point does (cv::undistortPoints for one point): remove K, five fixed-point iterations of
+// the inverse radial-tangential model, result rounded to float like cv::Point2f
+inline void undistort_to_float(float u, float v, const double* c, float& xn, float& yn) {
+    const double ifx = 1. / c[0], ify = 1. / c[1];
+    const double x0 = ((double)u - c[2]) * ifx, y0 = ((double)v - c[3]) * ify;
+    double x = x0, y = y0;
+    if (c[4] != 0. || c[5] != 0. || c[6] != 0. || c[7] != 0.) {
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1. + (c[5] * r2 + c[4]) * r2);
+            const double dx = 2. * c[6] * x * y + c[7] * (r2 + 2. * x * x);
+            const double dy = c[6] * (r2 + 2. * y * y) + 2. * c[7] * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+    }
+    xn = (float)x; yn = (float)y;
+}
+
+// null vector of the 8x9 system by Gaussian elimination with complete pivoting; false if a pivot is below 1e-12
+bool null_vector_8x9(double (&A)[8][9], double (&f)[9]) {
+    int col_of[9];
+    for (int j = 0; j < 9; j++) col_of[j] = j;
+    for (int k = 0; k < 8; k++) {
+        int pi = k, pj = k;
+        double best = -1.;
+        for (int i = k; i < 8; i++)
+            for (int j = k; j < 9; j++) {
+                const double a = std::fabs(A[i][j]);
+                if (a > best) { best = a; pi = i; pj = j; }   // first maximum in row-major order
+            }
+        if (!(best >= 1e-12)) return false;
+        if (pi != k) for (int j = 0; j < 9; j++) std::swap(A[k][j], A[pi][j]);
+        if (pj != k) {
+            for (int i = 0; i < 8; i++) std::swap(A[i][k], A[i][pj]);
+            std::swap(col_of[k], col_of[pj]);
+        }
+        const double inv = 1. / A[k][k];
+        for (int i = k + 1; i < 8; i++) {
+            const double m = A[i][k] * inv;
+            for (int j = k; j < 9; j++) A[i][j] = A[i][j] - m * A[k][j];
+        }
+    }
+    double y[9];
+    y[8] = 1.;
+    for (int k = 7; k >= 0; k--) {
+        double acc = 0.;
+        for (int j = k + 1; j < 9; j++) acc = acc + A[k][j] * y[j];
+        y[k] = -acc / A[k][k];
+    }
+    for (int j = 0; j < 9; j++) f[col_of[j]] = y[j];
+    return true;
+}
+
+inline bool is_inlier(const double (&F)[9], float x1, float y1, float x2, float y2, float thr2) {
+    double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+    const double s2 = 1. / (a * a + b * b), d2 = x2 * a + y2 * b + c;
+    a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
+    const double s1 = 1. / (a * a + b * b), d1 = x1 * a + y1 * b + c;
+    const float err = (float)std::max(d1 * d1 * s1, d2 * d2 * s2);
+    return err <= thr2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* status, int n, const double* calib8_prev,
+                        const double* calib8_next, int hypotheses, uint32_t seed, double* F_out) {
+    if (!prev_xy || !next_xy || !status || !calib8_prev || !calib8_next || n < 0) return -1;
+    if (hypotheses <= 0) hypotheses = 256;
+    if (n < 8) {
+        for (int i = 0; i < n; i++) status[i] = 0;
+        return -1;
+    }
+    std::vector<float> m((size_t)n * 4);   // x1 y1 x2 y2, normalized
+    for (int i = 0; i < n; i++) {
+        undistort_to_float(prev_xy[2 * i], prev_xy[2 * i + 1], calib8_prev, m[4 * i], m[4 * i + 1]);
+        undistort_to_float(next_xy[2 * i], next_xy[2 * i + 1], calib8_next, m[4 * i + 2], m[4 * i + 3]);
+    }
+    const double fmax = std::max(std::max(calib8_prev[0], calib8_prev[1]), std::max(calib8_next[0], calib8_next[1]));
+    const float thr = (float)(1. / fmax), thr2 = thr * thr;
+    int best_h = -1, best_count = 7;   // a model needs at least 8 inliers
+    double best_F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int h = 0; h < hypotheses; h++) {
+        int idx[8];
+        uint32_t draw = 0;
+        for (int k = 0; k < 8; k++) {
+            for (;;) {
+                const uint32_t r = mix32(seed ^ mix32((uint32_t)h * 0x9E3779B9u + 0x85EBCA6Bu * draw));
+                draw++;
+                const int cand = (int)(r % (uint32_t)n);
+                bool dup = false;
+                for (int q = 0; q < k; q++) dup |= idx[q] == cand;
+                if (!dup) { idx[k] = cand; break; }
+            }
+        }
+        double A[8][9], F[9];
+        for (int k = 0; k < 8; k++) {
+            const double x1 = m[4 * idx[k]], y1 = m[4 * idx[k] + 1], x2 = m[4 * idx[k] + 2], y2 = m[4 * idx[k] + 3];
+            A[k][0] = x2 * x1; A[k][1] = x2 * y1; A[k][2] = x2;
+            A[k][3] = y2 * x1; A[k][4] = y2 * y1; A[k][5] = y2;
+            A[k][6] = x1;      A[k][7] = y1;      A[k][8] = 1.;
+        }
+        if (!null_vector_8x9(A, F)) continue;
+        int count = 0;
+        for (int i = 0; i < n; i++) count += is_inlier(F, m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3], thr2) ? 1 : 0;
+        if (count > best_count) { best_count = count; best_h = h; for (int q = 0; q < 9; q++) best_F[q] = F[q]; }
+    }
+    if (best_h < 0) {
+        for (int i = 0; i < n; i++) status[i] = 0;
+        return -1;
+    }
+    for (int i = 0; i < n; i++)
+        if (!is_inlier(best_F, m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3], thr2)) status[i] = 0;
+    if (F_out) for (int q = 0; q < 9; q++) F_out[q] = best_F[q];
+    return best_h;
+}
+
 }  // extern "C"

@@ -25,6 +25,7 @@ extern "C" {
 #define FTO_LK_USE_INITIAL_FLOW 4
 #define FTO_LK_GET_MIN_EIGENVALS 8
 #define FTO_LK_FORWARD_BACKWARD 256 /* build-defined: see fto_lk_track */
+#define FTO_LK_REJECT_OUTLIERS 512  /* build-defined: see fto_reject_outliers (applied by the tracker backend) */
 
 typedef struct fto_pyramid fto_pyramid;
 
@@ -97,6 +98,23 @@ void fto_predict_flow(const float* K4, const float* R_p_c, const float* xy, floa
 
 /* H = K * R * K^-1 as used by fto_predict_flow, row-major float[9]. */
 void fto_homography(const float* K4, const float* R_p_c, float* H);
+
+/* Outlier rejection after LK (src/track/TrackKLT.cpp:405-424: undistort_point on both point sets, then
+ * cv::findFundamentalMat(FM_RANSAC, 1/max_focal, 0.999)).  OpenCV's RANSAC draws its samples from its own random
+ * number generator, so its inlier set cannot be reproduced without OpenCV; this is the build's own, fully specified
+ * variant with the same model, error measure and threshold:
+ *   - both point sets are undistorted like TrackBase::undistort_point (src/track/TrackBase.h:289-332) and rounded to
+ *     float, calib8 = fx, fy, cx, cy, k1, k2, p1, p2;
+ *   - `hypotheses` models (0 = 256) are fitted, model h from the 8 distinct pairs drawn by a counter-based hash of
+ *     (seed, h, draw number); the null vector of the 8x9 epipolar system comes from Gaussian elimination with complete
+ *     pivoting in double precision (a sample whose pivot falls below 1e-12 is skipped);
+ *   - a pair is an inlier of a model if (float)max(d1^2*s1, d2^2*s2) <= thr^2, the symmetric epipolar distance of
+ *     OpenCV's estimator, thr = 1 / max(fx, fy of both cameras);
+ *   - the model with the most inliers wins, the lower index on ties; status[i] &= inlier[i]; no model with at least
+ *     8 inliers, or fewer than 8 pairs: every status becomes 0.
+ * All n pairs take part, tracked or not, as in the reference.  Returns the winning model index or -1. */
+int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* status, int n, const double* calib8_prev,
+                        const double* calib8_next, int hypotheses, uint32_t seed, double* F_out);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,8 @@ public:
             }
             fto_lk_track(at(J.stream_prev, J.slot_prev)->pyr, at(J.stream_next, J.slot_next)->pyr, J.prev_xy, J.next_xy, J.status,
                          J.err, J.n, &pj, outer ? 1 : g_threads, J.iters);
+            if ((prm->flags & FT_LK_REJECT_OUTLIERS) && J.calib_prev && J.calib_next)
+                fto_reject_outliers(J.prev_xy, J.next_xy, J.status, J.n, J.calib_prev, J.calib_next, prm->ransac_hypotheses, prm->ransac_seed, nullptr);
         });
         return FT_OK;
     }

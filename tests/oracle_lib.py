@@ -12,6 +12,7 @@ LIB = os.path.join(ORACLE_DIR, "libft_oracle.so")
 LK_USE_INITIAL_FLOW = 4
 LK_GET_MIN_EIGENVALS = 8
 LK_FORWARD_BACKWARD = 256
+LK_REJECT_OUTLIERS = 512
 
 
 class fto_lk_params(C.Structure):
@@ -175,3 +176,18 @@ def predict_flow(K4, R, xy):
     out = np.zeros_like(xy)
     lib().fto_predict_flow(K4.ctypes.data, R.ctypes.data, xy.ctypes.data, out.ctypes.data, xy.shape[0])
     return out
+
+
+def reject_outliers(prev_xy, next_xy, status, calib8_prev, calib8_next=None, hypotheses=256, seed=0):
+    """Returns (status & inlier mask, winning model index or -1, F 3x3)."""
+    prev_xy = np.ascontiguousarray(prev_xy, dtype=np.float32).reshape(-1, 2)
+    next_xy = np.ascontiguousarray(next_xy, dtype=np.float32).reshape(-1, 2)
+    st = np.ascontiguousarray(status, dtype=np.uint8).copy()
+    c0 = np.ascontiguousarray(calib8_prev, dtype=np.float64)
+    c1 = c0 if calib8_next is None else np.ascontiguousarray(calib8_next, dtype=np.float64)
+    F = np.zeros(9, dtype=np.float64)
+    L = lib()
+    L.fto_reject_outliers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    h = L.fto_reject_outliers(prev_xy.ctypes.data, next_xy.ctypes.data, st.ctypes.data, prev_xy.shape[0], c0.ctypes.data, c1.ctypes.data,
+                              hypotheses, seed, F.ctypes.data)
+    return st, h, F.reshape(3, 3)

@@ -59,3 +59,52 @@ def render(f, w, h, dx=0.0, dy=0.0):
 def random_points(w, h, n, seed=0, border=0.0):
     rng = np.random.default_rng(seed)
     return np.stack([rng.uniform(border, w - 1 - border, n), rng.uniform(border, h - 1 - border, n)], axis=1).astype(np.float32)
+
+
+def two_view_matches(n, n_outliers, calib8, seed=0, t=(0.3, 0.02, 0.05), rot=(0.01, -0.03, 0.02), noise_px=0.15):
+    """Pixel correspondences of n random 3-D points seen by a camera before and after a rigid motion (Brown distortion
+    applied), the last n_outliers of them replaced by random pixels.  Returns (prev_xy, next_xy, is_outlier)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy, k1, k2, p1, p2 = calib8
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.3, 1.3, n), rng.uniform(3, 9, n)], axis=1)
+    rx, ry, rz = rot
+    Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+    Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+    Rz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+
+    def project(P):
+        x, y = P[:, 0] / P[:, 2], P[:, 1] / P[:, 2]
+        r2 = x * x + y * y
+        cd = 1 + k1 * r2 + k2 * r2 * r2
+        xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        return np.stack([fx * xd + cx, fy * yd + cy], axis=1)
+
+    a = project(X) + rng.normal(0, noise_px, (n, 2))
+    b = project(X @ R.T + np.asarray(t)) + rng.normal(0, noise_px, (n, 2))
+    out = np.zeros(n, dtype=bool)
+    if n_outliers:
+        out[n - n_outliers:] = True
+        b[out] = np.stack([rng.uniform(0, 2 * cx, n_outliers), rng.uniform(0, 2 * cy, n_outliers)], axis=1)
+    return a.astype(np.float32), b.astype(np.float32), out
+
+
+def with_moving_patches(frames, size=96, seed=0, velocities=((4.0, 0.0), (0.0, -3.0), (-3.0, 3.0))):
+    """Copy of a frame stack with textured square patches pasted in, each drifting with its own constant velocity
+    (px/frame): features on them track well but move against the rest of the scene, which is what outlier rejection is
+    meant to catch.  Several directions, because one translating patch over a planar scene still fits an epipolar
+    geometry (epipole at infinity along its direction)."""
+    rng = np.random.default_rng(seed)
+    out = np.array(frames, copy=True)
+    n, h, w = out.shape
+    for k, (vx, vy) in enumerate(velocities):
+        coarse = rng.integers(0, 2, (size // 8, size // 8)) * 170 + 40
+        tex = np.kron(coarse, np.ones((8, 8))).astype(np.uint8)
+        x0 = w * (k + 1) / (len(velocities) + 1) - size / 2 - vx * n / 2
+        y0 = h / 2 - size / 2 - vy * n / 2 + (k % 2) * h / 5 - h / 10
+        for i in range(n):
+            x, y = int(round(x0 + vx * i)), int(round(y0 + vy * i))
+            x, y = min(max(x, 0), w - size), min(max(y, 0), h - size)
+            out[i, y:y + size, x:x + size] = tex
+    return out

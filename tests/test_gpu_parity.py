@@ -233,6 +233,65 @@ def test_fast_grid_batched_and_plateaus(dev):
         assert np.array_equal(out[i, : n_out[i]], ref)
 
 
+CALIBS = [np.array([458.7, 457.3, 367.2, 248.4, -0.28, 0.074, 2e-4, 2e-5]), np.array([600., 600., 376., 240., 0, 0, 0, 0])]
+
+
+@pytest.mark.parametrize("n,n_out,seed", [(150, 30, 1), (8, 0, 2), (400, 200, 3), (64, 50, 4)])
+def test_reject_outliers_equals_oracle(dev, n, n_out, seed):
+    """Standalone rejection on synthetic two-view matches: the status bytes equal the CPU checker's bit for bit
+    (same hash-drawn samples, same double-precision elimination, same float error measure)."""
+    ctx = _ctx(dev, 64, 64, max_points=1200)
+    sets, want = [], []
+    rng = np.random.default_rng(seed)
+    for k, calib in enumerate(CALIBS):
+        prev, nxt, _ = synth.two_view_matches(n, n_out, calib, seed=seed * 10 + k)
+        status = (rng.random(n) > 0.1).astype(np.uint8)
+        sets.append(dict(prev_xy=prev, next_xy=nxt, status=status, calib_prev=calib, calib_next=CALIBS[1 - k]))
+        want.append(O.reject_outliers(prev, nxt, status, calib, CALIBS[1 - k], hypotheses=200, seed=seed)[0])
+    with ctx:
+        got = ctx.reject_outliers(sets, hypotheses=200, seed=seed)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    assert sum(int(w_.sum()) for w_ in want) > 0
+
+
+def test_reject_outliers_degenerate_sets(dev):
+    calib = CALIBS[0]
+    prev, nxt, _ = synth.two_view_matches(100, 0, calib, seed=5)
+    with _ctx(dev, 64, 64, max_points=600) as ctx:
+        few = ctx.reject_outliers([dict(prev_xy=prev[:7], next_xy=nxt[:7], calib_prev=calib)])[0]
+        assert not few.any()                                                  # fewer than 8 points: no model
+        flat = ctx.reject_outliers([dict(prev_xy=prev, next_xy=prev * 0 + 5.0, calib_prev=calib)])[0]
+        assert np.array_equal(flat, O.reject_outliers(prev, prev * 0 + 5.0, np.ones(100, np.uint8), calib)[0])
+        empty = ctx.reject_outliers([dict(prev_xy=prev[:0], next_xy=nxt[:0], calib_prev=calib),
+                                     dict(prev_xy=prev, next_xy=nxt, calib_prev=calib)])
+        assert len(empty[0]) == 0 and np.array_equal(empty[1], O.reject_outliers(prev, nxt, np.ones(100, np.uint8), calib)[0])
+        with pytest.raises(dev.FtError):                                  # more points than the context was sized for
+            ctx.reject_outliers([dict(prev_xy=np.zeros((601, 2)), next_xy=np.zeros((601, 2)), calib_prev=calib)])
+
+
+def test_lk_with_outlier_rejection_equals_lk_then_oracle_rejection(dev):
+    """FT_LK_REJECT_OUTLIERS = the plain LK result with the CPU checker's rejection applied to it."""
+    w, h = 640, 400
+    a, b = synth.shifted_pair(w, h, 3, -2, seed=11)
+    pts = synth.random_points(w, h, 300, seed=3)
+    calib = CALIBS[0]
+    job = dict(prev=(0, 0), next=(0, 1), prev_xy=pts, calib_prev=calib)
+    with _ctx(dev, w, h, max_points=600) as ctx:
+        ctx.upload(0, 0, a)
+        ctx.upload(0, 1, b)
+        ctx.build_pyramid([0, 0], [0, 1], 3, 21)
+        plain = ctx.lk_track([job], dev.LKParams(21, 3))[0]
+        strict = ctx.lk_track([job], dev.LKParams(21, 3, flags=dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_REJECT_OUTLIERS,
+                                                  ransac_hypotheses=128, ransac_seed=9))[0]
+        with pytest.raises(dev.FtError):                                  # the flag needs the camera models
+            ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)],
+                         dev.LKParams(21, 3, flags=dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_REJECT_OUTLIERS))
+    assert np.array_equal(plain[0], strict[0]) and np.array_equal(plain[2], strict[2])      # positions, residuals untouched
+    want = O.reject_outliers(pts, plain[0], plain[1], calib, hypotheses=128, seed=9)[0]
+    assert np.array_equal(strict[1], want)
+
+
 def test_error_codes(dev):
     with _ctx(dev, 128, 96, n_streams=1) as ctx:
         with pytest.raises(dev.FtError) as e:

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import synth as tsynth
 from feature_tracker_amd import synth, tracker
 
 pytestmark = pytest.mark.gpu
@@ -45,12 +46,28 @@ def test_batch_tracker_matches_cpu_checker(opts):
     assert gpu[-1][0] > 250
 
 
-def test_stereo_tracker_matches_cpu_checker():
+def test_batch_tracker_with_outlier_rejection_matches_cpu_checker():
+    """Scenes with independently moving patches; the rejection kernel must drop exactly the features the CPU
+    checker drops (same seeded hypotheses, same arithmetic), frame after frame."""
+    O.lib()
+    seqs = [synth.Sequence(752, 480, 8, stream_id=40 + s) for s in range(3)]
+    for s, q in enumerate(seqs):
+        q.frames = tsynth.with_moving_patches(q.frames, seed=s)
+    opts = dict(win_size=21, use_gyro_seed=1, reject_outliers=1)
+    gpu = _feed_all(tracker.BatchTracker(3, 752, 480, **opts), seqs, 8)
+    cpu = _feed_all(tracker.BatchTracker(3, 752, 480, lib_path=ORC, **opts), seqs, 8)
+    _same_run(gpu, cpu)
+    loose = _feed_all(tracker.BatchTracker(3, 752, 480, win_size=21, use_gyro_seed=1), seqs, 2)
+    assert gpu[1][1] == loose[1][1] and gpu[1][0] <= loose[1][0] - 20   # the patches' features went
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(reject_outliers=1)])
+def test_stereo_tracker_matches_cpu_checker(opts):
     O.lib()
     q = synth.Sequence(640, 400, 8, stream_id=7)
     runs = []
     for lib_path in (None, ORC):
-        t = tracker.Tracker(640, 400, lib_path=lib_path, win_size=15)
+        t = tracker.Tracker(640, 400, lib_path=lib_path, win_size=15, **opts)
         t.set_calibration(np.stack([q.calib8, q.calib8]), np.stack([q.T_cam_imu, q.T_cam_imu]))
         hist = []
         for i in range(8):

@@ -258,3 +258,41 @@ def test_gyro_seed_pure_rotation():
     assert np.abs(out[:, 0] - ex).max() < 2e-3 and np.abs(out[:, 1] - ey).max() < 2e-3
     # identity rotation leaves points where they are
     assert np.abs(O.predict_flow(K4, np.eye(3), pts) - pts).max() < 1e-3
+
+
+# ---- outlier rejection (fundamental-matrix RANSAC, the build's own seeded definition) ----
+
+@pytest.mark.parametrize("calib8,t", [((460.0, 458.0, 376.0, 240.0, 0.0, 0.0, 0.0, 0.0), (0.3, 0.02, 0.05)),
+                                      ((460.0, 458.0, 376.0, 240.0, -0.28, 0.07, 2e-4, 2e-5), (0.3, 0.02, 0.05)),
+                                      ((460.0, 458.0, 376.0, 240.0, 0.0, 0.0, 0.0, 0.0), (0.25, 0.0, 0.0))])   # pure sideways: F33 = 0
+def test_reject_outliers_separates_random_matches(calib8, t):
+    import synth
+    prev, nxt, is_out = synth.two_view_matches(150, 30, calib8, seed=3, t=t)
+    st, h, F = O.reject_outliers(prev, nxt, np.ones(150, np.uint8), calib8, seed=7)
+    assert h >= 0
+    assert st[~is_out].mean() >= 0.95          # nearly every true match survives
+    assert st[is_out].mean() <= 0.15           # nearly every random match is rejected
+    # the winning model is a fundamental matrix of the normalized points: x2^T F x1 ~ 0 on the true matches
+    def norm(p):
+        return np.stack([(p[:, 0] - calib8[2]) / calib8[0], (p[:, 1] - calib8[3]) / calib8[1], np.ones(len(p))], axis=1)
+    if not any(calib8[4:]):
+        r = np.abs(np.einsum("ij,jk,ik->i", norm(nxt[~is_out]), F, norm(prev[~is_out]))) / np.linalg.norm(F)
+        assert np.median(r) < 2e-3
+
+
+def test_reject_outliers_is_deterministic_and_keeps_lost_points_lost():
+    import synth
+    calib8 = (460.0, 458.0, 376.0, 240.0, -0.1, 0.01, 0.0, 0.0)
+    prev, nxt, is_out = synth.two_view_matches(80, 10, calib8, seed=5)
+    status = np.ones(80, np.uint8)
+    status[::7] = 0                                               # points LK had already lost
+    a = O.reject_outliers(prev, nxt, status, calib8, seed=1)
+    b = O.reject_outliers(prev, nxt, status, calib8, seed=1)
+    c = O.reject_outliers(prev, nxt, status, calib8, seed=2)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+    assert not a[0][::7].any()                                    # status is only ever cleared
+    assert a[1] != c[1] or np.array_equal(a[0], c[0])             # another seed draws other samples
+    few = O.reject_outliers(prev[:7], nxt[:7], np.ones(7, np.uint8), calib8)
+    assert few[1] == -1 and not few[0].any()                      # fewer than 8 pairs: nothing survives
+    flat = O.reject_outliers(prev, prev * 0 + 5.0, np.ones(80, np.uint8), calib8)
+    assert flat[1] == -1 and not flat[0].any()                    # degenerate data: no model

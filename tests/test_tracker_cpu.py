@@ -113,6 +113,26 @@ def test_forward_backward_option_is_stricter(seq):
     assert fb[-1][0] <= plain[-1][0]
 
 
+def test_outlier_rejection_drops_independently_moving_features(seq):
+    """Features on patches that drift against the scene track well but break the epipolar geometry: with the option
+    on they are dropped, without it they stay (src/track/TrackKLT.cpp:405-424)."""
+    import synth as tsynth
+    frames = tsynth.with_moving_patches(seq.frames[:8])
+
+    def run(**opts):
+        b = tracker.BatchTracker(1, seq.w, seq.h, lib_path=ORC, win_size=21, **opts)
+        b.set_calibration(0, seq.calib8, seq.T_cam_imu)
+        return [b.feed_host([seq.timestamps[i]], [frames[i]]) for i in range(8)]
+
+    plain, strict = run(), run(reject_outliers=1)
+    assert plain[1][1] == strict[1][1] and strict[1][0] <= plain[1][0] - 10      # same attempts, >= 10 more rejected
+    assert strict[1][0] >= 0.7 * plain[1][0]                                     # the static scene survives
+    assert run(reject_outliers=1) == strict                                      # seeded: repeatable
+    clean = [tracker_counts for tracker_counts in _run(seq, 6, win_size=21, reject_outliers=1)]
+    base = _run(seq, 6, win_size=21)
+    assert [c[0] for c in clean] == [c[0] for c in base]                         # nothing to reject in a rigid scene
+
+
 def test_stereo_feed_tracks_both_cameras_and_fills_database(seq):
     t = tracker.Tracker(seq.w, seq.h, lib_path=ORC, win_size=15)
     t.set_calibration(np.stack([seq.calib8, seq.calib8]), np.stack([seq.T_cam_imu, seq.T_cam_imu]))
