@@ -81,7 +81,7 @@ struct ft_ctx {
     uint8_t* lk_out_host = nullptr; uint8_t* lk_out_dev = nullptr; size_t lk_out_bytes = 0;
     uint8_t* lk_out_host_dev = nullptr;   // device-side address of lk_out_host
     float4* lk_norm_dev = nullptr;        // outlier rejection: normalized point pairs
-    double* ransac_sys_dev = nullptr;     // outlier rejection: 8x9 systems, allocated on first use
+    RansacPartial* ransac_part_dev = nullptr;   // outlier rejection: best model of every workgroup
     PendingLK lk_pending;
 
     // FAST scratch
@@ -229,6 +229,11 @@ int sync_and_deliver(ft_ctx* c) {
     return deliver_pending(c, ~0ull);
 }
 
+void launch_reject(ft_ctx* c, const OutlierArgs& o, int n_jobs) {
+    hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3(n_jobs * RO_WG_PER_JOB), dim3(256), 0, c->q, o, c->ransac_part_dev);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_jobs), dim3(256), 0, c->q, o, c->ransac_part_dev);
+}
+
 int pick_seglen(int win_w, int win_h) {
     const int opts[3] = {4, 8, 16};
     for (int s : opts) {
@@ -373,6 +378,8 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lk_out_dev = (uint8_t*)p;
     if (hipMalloc(&p, sizeof(float4) * N) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_norm_dev = (float4*)p;
+    if (hipMalloc(&p, sizeof(RansacPartial) * RO_WG_PER_JOB * FT_MAX_BATCH) != hipSuccess) return fail(FT_E_NOMEM);
+    c->ransac_part_dev = (RansacPartial*)p;
 
     // FAST scratch
     c->cand_entries_per_img = ((size_t)lim->max_width + 2 * 64) * ((size_t)lim->max_height + 2 * 64) / 4 + (size_t)lim->max_grid_cells;
@@ -421,7 +428,7 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
-    if (c->ransac_sys_dev) (void)hipFree(c->ransac_sys_dev);
+    if (c->ransac_part_dev) (void)hipFree(c->ransac_part_dev);
     if (c->cand) (void)hipFree(c->cand);
     if (c->cand_count) (void)hipFree(c->cand_count);
     for (auto& h : c->fast_out_host) if (h) (void)hipHostFree(h);
@@ -671,11 +678,6 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     if (reject) {
         // final mask on the device; the kernel also moves positions, residuals and status into the pinned host block
-        if (!c->ransac_sys_dev) {
-            void* p = nullptr;
-            FT_HIP(c, hipMalloc(&p, sizeof(double) * 72 * 256 * FT_MAX_BATCH));
-            c->ransac_sys_dev = (double*)p;
-        }
         OutlierArgs o;
         o.jobs = a.jobs;
         o.prev_xy = a.prev_xy; o.next_xy = a.next_xy; o.err = a.err; o.status = a.status;
@@ -685,7 +687,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         o.out_status = c->lk_out_host_dev + 12 * N;
         o.hypotheses = prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 256;
         o.seed = prm->ransac_seed;
-        hipLaunchKernelGGL(reject_outliers_kernel, dim3(n_jobs), dim3(256), 0, c->q, o, c->ransac_sys_dev);
+        launch_reject(c, o, n_jobs);
         FT_HIP(c, hipGetLastError());
         if (want_iters)
             FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
@@ -742,11 +744,6 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
     const int n16 = (int)((off_next + 8 * N + 15) / 16);
     hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->q, reinterpret_cast<const uint4*>(c->lk_in_host_dev),
                        reinterpret_cast<uint4*>(c->lk_in_dev), n16);
-    if (!c->ransac_sys_dev) {
-        void* p = nullptr;
-        FT_HIP(c, hipMalloc(&p, sizeof(double) * 72 * 256 * FT_MAX_BATCH));
-        c->ransac_sys_dev = (double*)p;
-    }
     OutlierArgs o;
     o.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
     o.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);
@@ -759,7 +756,7 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
     o.out_status = c->lk_out_host_dev + 12 * N;
     o.hypotheses = hypotheses > 0 ? hypotheses : 256;
     o.seed = seed;
-    hipLaunchKernelGGL(reject_outliers_kernel, dim3(n_sets), dim3(256), 0, c->q, o, c->ransac_sys_dev);
+    launch_reject(c, o, n_sets);
     FT_HIP(c, hipGetLastError());
     PendingLK& P = c->lk_pending;
     P.jobs = std::move(deliver);

@@ -1,5 +1,5 @@
 // Outlier rejection after LK for gfx950: undistortion of both point sets and a seeded RANSAC on the fundamental
-// matrix, one 256-thread workgroup per LK job (= per image pair), one hypothesis per thread.
+// matrix.
 //
 // Replaces the tail of TrackKLT::perform_matching (reference: src/track/TrackKLT.cpp:405-424): undistort_point on
 // both point sets (src/track/TrackBase.h:289-332), cv::findFundamentalMat(FM_RANSAC, 1/max_focal, 0.999) and the
@@ -7,9 +7,14 @@
 // is the build's own (a counter-based hash); model, error measure and threshold are OpenCV's.  The arithmetic is
 // double precision in a fixed order, so the result equals the CPU checker's bit for bit.
 //
-// The work is tiny next to LK (256 eliminations of an 8x9 system and 256 x n error evaluations per image pair); the
-// kernel exists so that the tracking results never leave the device before the final mask is known.  It also moves
-// the results of the batch into the pinned host block (positions, residuals, final status).
+// Two launches per batch of image pairs:
+//   ransac_hypotheses_kernel  eight workgroups per image pair, 32 hypotheses each.  A hypothesis is solved by eight
+//                             lanes, one per equation of the 8x9 system, each holding its row in registers; pivot
+//                             search and the pivot row travel by lane shuffles, so the elimination touches no
+//                             memory.  The inlier count of the 32 models is then shared by all 256 threads
+//                             (32 models x 8 slices of the point set, points read from LDS).
+//   ransac_select_kernel      one workgroup per image pair: best of the eight partial winners, final mask, and the
+//                             batch results (positions, residuals, status) written into the pinned host block.
 #pragma once
 #include "ft_kernels_lk.hpp"
 
@@ -65,133 +70,179 @@ __device__ __forceinline__ bool ro_inlier(const double* F, float4 m, float thr2)
     return err <= thr2;
 }
 
-// null vector of the 8x9 system by Gaussian elimination with complete pivoting (rows of A are in LDS, one system
-// per thread, element (i, j) at A[(i * 9 + j) * 256]); false if a pivot is below 1e-12
-__device__ bool ro_null_vector(double* A, double* f) {
-    int col_of[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) col_of[j] = j;
-#define RO_A(i, j) A[((i) * 9 + (j)) * 256]
-    for (int k = 0; k < 8; k++) {
-        int pi = k, pj = k;
-        double best = -1.;
-        for (int i = k; i < 8; i++)
-            for (int j = k; j < 9; j++) {
-                const double a = fabs(RO_A(i, j));
-                if (a > best) { best = a; pi = i; pj = j; }   // first maximum in row-major order
-            }
-        if (!(best >= 1e-12)) return false;
-        if (pi != k)
-            for (int j = 0; j < 9; j++) { const double t = RO_A(k, j); RO_A(k, j) = RO_A(pi, j); RO_A(pi, j) = t; }
-        if (pj != k) {
-            for (int i = 0; i < 8; i++) { const double t = RO_A(i, k); RO_A(i, k) = RO_A(i, pj); RO_A(i, pj) = t; }
-            int tc = 0, tk = 0;
-#pragma unroll
-            for (int j = 0; j < 9; j++) { if (j == k) tk = col_of[j]; if (j == pj) tc = col_of[j]; }
-#pragma unroll
-            for (int j = 0; j < 9; j++) { if (j == k) col_of[j] = tc; else if (j == pj) col_of[j] = tk; }
-        }
-        const double inv = 1. / RO_A(k, k);
-        for (int i = k + 1; i < 8; i++) {
-            const double m = RO_A(i, k) * inv;
-            for (int j = k; j < 9; j++) RO_A(i, j) = RO_A(i, j) - m * RO_A(k, j);
-        }
-    }
-    double y[9];
-    y[8] = 1.;
-#pragma unroll
-    for (int k = 7; k >= 0; k--) {
-        double acc = 0.;
-#pragma unroll
-        for (int j = k + 1; j < 9; j++) acc = acc + RO_A(k, j) * y[j];
-        y[k] = -acc / RO_A(k, k);
-    }
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-#pragma unroll
-        for (int q = 0; q < 9; q++)
-            if (col_of[j] == q) f[q] = y[j];
-    }
-#undef RO_A
-    return true;
-}
+constexpr int RO_HYP_PER_WG = 32;     // hypotheses per workgroup (8 lanes each)
+constexpr int RO_WG_PER_JOB = 8;      // 8 x 32 = 256 hypotheses at most
+constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest is read from the global copy
 
-// 8x9 doubles per thread do not fit LDS for 256 threads (147 KB), so the systems live in a global scratch laid out
-// [element][job * 256 + thread]; elimination traffic stays in L2
-__global__ void __launch_bounds__(256) reject_outliers_kernel(OutlierArgs a, double* __restrict__ sys_scratch) {
-    __shared__ double best_F[9];
-    __shared__ int red_count[256];
-    __shared__ int winner;
+struct RansacPartial {   // best model of one workgroup
+    int count;           // inliers, -1 = none with at least 8
+    int hyp;             // hypothesis index
+    double F[9];
+};
+
+// element j of a nine-element register array (a macro on purpose: behind a function boundary the compiler turns the
+// select chain into an indexed load and the array moves to scratch memory)
+#define RO_PICK9(v, j)                                                                                              \
+    ((j) == 8 ? (v)[8] : (j) == 7 ? (v)[7] : (j) == 6 ? (v)[6] : (j) == 5 ? (v)[5] : (j) == 4 ? (v)[4] : (j) == 3 ? (v)[3] \
+     : (j) == 2 ? (v)[2] : (j) == 1 ? (v)[1] : (v)[0])
+
+__global__ void __launch_bounds__(256) ransac_hypotheses_kernel(OutlierArgs a, RansacPartial* __restrict__ part) {
+    __shared__ float4 nl[RO_NORM_LDS];
+    __shared__ double Fs[RO_HYP_PER_WG][9];
+    __shared__ int valid[RO_HYP_PER_WG];
+    __shared__ int cnt[RO_HYP_PER_WG];
     const int t = threadIdx.x;
-    const LKJobDev* job = a.jobs + blockIdx.x;
+    const int job_i = blockIdx.x / RO_WG_PER_JOB, h0 = (blockIdx.x % RO_WG_PER_JOB) * RO_HYP_PER_WG;
+    const LKJobDev* job = a.jobs + job_i;
     const int first = job->first, n = job->count;
+    RansacPartial* out = part + blockIdx.x;
+    if (n < 8 || h0 >= a.hypotheses) {   // uniform for the workgroup
+        if (t == 0) { out->count = -1; out->hyp = h0; }
+        return;
+    }
     const double* c0 = job->calib;        // template image camera
     const double* c1 = job->calib + 8;    // target image camera
 
-    // ---- normalized coordinates of both point sets ----
+    // ---- normalized coordinates of both point sets (every workgroup of the pair writes the same values) ----
     for (int i = t; i < n; i += 256) {
         const float2 p = ro_undistort(a.prev_xy[2 * (first + i)], a.prev_xy[2 * (first + i) + 1], c0);
         const float2 q = ro_undistort(a.next_xy[2 * (first + i)], a.next_xy[2 * (first + i) + 1], c1);
-        a.norm[first + i] = make_float4(p.x, p.y, q.x, q.y);
+        const float4 m = make_float4(p.x, p.y, q.x, q.y);
+        a.norm[first + i] = m;
+        if (i < RO_NORM_LDS) nl[i] = m;
     }
-    __syncthreads();   // also orders the global writes above before the reads below (same workgroup)
+    if (t < RO_HYP_PER_WG) cnt[t] = 0;
+    __syncthreads();   // also orders this workgroup's global writes above before its reads below
 
     const double f0 = c0[0] < c0[1] ? c0[1] : c0[0], f1 = c1[0] < c1[1] ? c1[1] : c1[0];
     const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
 
-    // ---- one hypothesis per thread ----
-    int count = -1;
-    double F[9];
-    if (n >= 8 && t < a.hypotheses) {
-        int idx[8];
-        uint32_t draw = 0;
-        for (int k = 0; k < 8; k++) {
-            for (;;) {
-                const uint32_t r = ro_mix32(a.seed ^ ro_mix32((uint32_t)t * 0x9E3779B9u + 0x85EBCA6Bu * draw));
-                draw++;
-                const int cand = (int)(r % (uint32_t)n);
-                bool dup = false;
+    // ---- one hypothesis per eight lanes, lane r holds equation r ----
+    {
+        const int r = t & 7, hl = t >> 3, h = h0 + hl;
+        const int gbase = (t & 63) & ~7;
+        int mine = 0;
+        {
+            int idx[8];
+            uint32_t draw = 0;
 #pragma unroll
-                for (int q = 0; q < 8; q++) dup |= (q < k) && idx[q] == cand;
-                if (!dup) {
+            for (int k = 0; k < 8; k++) {
+                for (;;) {
+                    const uint32_t rnd = ro_mix32(a.seed ^ ro_mix32((uint32_t)h * 0x9E3779B9u + 0x85EBCA6Bu * draw));
+                    draw++;
+                    const int cand = (int)(rnd % (uint32_t)n);
+                    bool dup = false;
 #pragma unroll
-                    for (int q = 0; q < 8; q++) if (q == k) idx[q] = cand;
-                    break;
+                    for (int q = 0; q < 8; q++) dup |= (q < k) && idx[q] == cand;
+                    if (!dup) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) idx[q] = (q == k) ? cand : idx[q];
+                        break;
+                    }
                 }
             }
-        }
-        double* A = sys_scratch + (size_t)blockIdx.x * 72 * 256 + t;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float4 m = a.norm[first + idx[k]];
-            const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
-            A[(k * 9 + 0) * 256] = x2 * x1; A[(k * 9 + 1) * 256] = x2 * y1; A[(k * 9 + 2) * 256] = x2;
-            A[(k * 9 + 3) * 256] = y2 * x1; A[(k * 9 + 4) * 256] = y2 * y1; A[(k * 9 + 5) * 256] = y2;
-            A[(k * 9 + 6) * 256] = x1;      A[(k * 9 + 7) * 256] = y1;      A[(k * 9 + 8) * 256] = 1.;
+            for (int k = 0; k < 8; k++) mine = (r == k) ? idx[k] : mine;
         }
-        if (ro_null_vector(A, F)) {
-            count = 0;
-            for (int i = 0; i < n; i++) count += ro_inlier(F, a.norm[first + i], thr2) ? 1 : 0;
+        const float4 m = mine < RO_NORM_LDS ? nl[mine] : a.norm[first + mine];
+        const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
+        double A[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.};
+        uint32_t colmask = 0;
+        bool row_used = false, ok = true;
+        int my_pc = 0;
+#pragma unroll
+        for (int step = 0; step < 8; step++) {
+            // largest remaining entry: first in this row, then across the eight rows (ties: lowest row, lowest column)
+            double bm = -1.;
+            int brc = r << 4;
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const double v = fabs(A[j]);
+                const bool take = !row_used && !((colmask >> j) & 1u) && v > bm;
+                bm = take ? v : bm;
+                brc = take ? ((r << 4) | j) : brc;
+            }
+#pragma unroll
+            for (int sft = 1; sft < 8; sft <<= 1) {
+                const double om = __shfl_xor(bm, sft);
+                const int orc = __shfl_xor(brc, sft);
+                const bool take = om > bm || (om == bm && (orc >> 4) < (brc >> 4));
+                bm = take ? om : bm;
+                brc = take ? orc : brc;
+            }
+            if (!(bm >= 1e-12)) ok = false;   // same for the eight lanes; they run on (shuffles need all of them)
+            const int pr = brc >> 4, pc = brc & 15;
+            double P[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) P[j] = __shfl(A[j], gbase | pr);
+            const double inv = 1. / RO_PICK9(P, pc);
+            const double mult = RO_PICK9(A, pc) * inv;
+            colmask |= 1u << pc;
+            if (r == pr) {
+                row_used = true;
+                my_pc = pc;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    if (!((colmask >> j) & 1u)) A[j] = A[j] - mult * P[j];
+            }
+        }
+        const int free_col = __builtin_ctz(~colmask & 0x1ffu);
+        const double y = -RO_PICK9(A, free_col) / RO_PICK9(A, my_pc);
+        Fs[hl][my_pc] = y;
+        if (r == 0) {
+            Fs[hl][free_col] = 1.;
+            valid[hl] = (ok && h < a.hypotheses) ? 1 : 0;
         }
     }
+    __syncthreads();
+
+    // ---- inlier counts: 32 models x 8 slices of the point set ----
+    {
+        const int hh = t & 31, slice = t >> 5;
+        if (valid[hh]) {
+            double F[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
+            int c = 0;
+            for (int i = slice; i < n; i += 8) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
+            atomicAdd(&cnt[hh], c);
+        }
+    }
+    __syncthreads();
 
     // ---- most inliers wins, the lower hypothesis index on ties; at least 8 inliers ----
-    red_count[t] = count;
-    __syncthreads();
     if (t == 0) {
         int bh = -1, bc = 7;
-        for (int h = 0; h < 256; h++)
-            if (red_count[h] > bc) { bc = red_count[h]; bh = h; }
-        winner = bh;
+        for (int q = 0; q < RO_HYP_PER_WG; q++)
+            if (valid[q] && cnt[q] > bc) { bc = cnt[q]; bh = q; }
+        out->count = bh < 0 ? -1 : bc;
+        out->hyp = h0 + (bh < 0 ? 0 : bh);
+        if (bh >= 0)
+            for (int q = 0; q < 9; q++) out->F[q] = Fs[bh][q];
     }
-    __syncthreads();
-    if (t == winner) {
-#pragma unroll
-        for (int q = 0; q < 9; q++) best_F[q] = F[q];
-    }
-    __syncthreads();
+}
 
-    // ---- final status and the batch results, straight into the pinned host block ----
+__global__ void __launch_bounds__(256) ransac_select_kernel(OutlierArgs a, const RansacPartial* __restrict__ part) {
+    __shared__ double best_F[9];
+    __shared__ int winner;
+    const int t = threadIdx.x;
+    const LKJobDev* job = a.jobs + blockIdx.x;
+    const int first = job->first, n = job->count;
+    const double* c0 = job->calib;
+    const double* c1 = job->calib + 8;
+    const double f0 = c0[0] < c0[1] ? c0[1] : c0[0], f1 = c1[0] < c1[1] ? c1[1] : c1[0];
+    const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
+    if (t == 0) {
+        const RansacPartial* p = part + (size_t)blockIdx.x * RO_WG_PER_JOB;
+        int bw = -1, bc = 7;
+        for (int q = 0; q < RO_WG_PER_JOB; q++)      // ascending hypothesis ranges: a strict test keeps the lower index
+            if (p[q].count > bc) { bc = p[q].count; bw = q; }
+        winner = bw;
+        if (bw >= 0)
+            for (int q = 0; q < 9; q++) best_F[q] = p[bw].F[q];
+    }
+    __syncthreads();
     const bool have_model = winner >= 0;
     for (int i = t; i < n; i += 256) {
         const int g = first + i;
@@ -202,5 +253,7 @@ __global__ void __launch_bounds__(256) reject_outliers_kernel(OutlierArgs a, dou
         a.out_status[g] = keep ? 1 : 0;
     }
 }
+
+#undef RO_PICK9
 
 }  // namespace ftd

@@ -670,38 +670,39 @@ inline void undistort_to_float(float u, float v, const double* c, float& xn, flo
     xn = (float)x; yn = (float)y;
 }
 
-// null vector of the 8x9 system by Gaussian elimination with complete pivoting; false if a pivot is below 1e-12
+// Null vector of the 8x9 system by Gauss-Jordan elimination with complete pivoting; false if a pivot is below 1e-12.
+// Rows and columns are never moved: a step takes the largest remaining entry (ties: the lowest row, then the lowest
+// column), clears its column in every other row, and retires its row and column.  After eight steps every row holds
+// its own pivot and the one column that was never chosen, whose unknown is set to 1.
 bool null_vector_8x9(double (&A)[8][9], double (&f)[9]) {
-    int col_of[9];
-    for (int j = 0; j < 9; j++) col_of[j] = j;
-    for (int k = 0; k < 8; k++) {
-        int pi = k, pj = k;
+    bool row_used[8] = {false, false, false, false, false, false, false, false};
+    bool col_used[9] = {false, false, false, false, false, false, false, false, false};
+    int piv_col[8];
+    for (int step = 0; step < 8; step++) {
+        int pr = -1, pc = -1;
         double best = -1.;
-        for (int i = k; i < 8; i++)
-            for (int j = k; j < 9; j++) {
+        for (int i = 0; i < 8; i++) {
+            if (row_used[i]) continue;
+            for (int j = 0; j < 9; j++) {
+                if (col_used[j]) continue;
                 const double a = std::fabs(A[i][j]);
-                if (a > best) { best = a; pi = i; pj = j; }   // first maximum in row-major order
+                if (a > best) { best = a; pr = i; pc = j; }   // first maximum in row-major order
             }
+        }
         if (!(best >= 1e-12)) return false;
-        if (pi != k) for (int j = 0; j < 9; j++) std::swap(A[k][j], A[pi][j]);
-        if (pj != k) {
-            for (int i = 0; i < 8; i++) std::swap(A[i][k], A[i][pj]);
-            std::swap(col_of[k], col_of[pj]);
-        }
-        const double inv = 1. / A[k][k];
-        for (int i = k + 1; i < 8; i++) {
-            const double m = A[i][k] * inv;
-            for (int j = k; j < 9; j++) A[i][j] = A[i][j] - m * A[k][j];
+        row_used[pr] = true; col_used[pc] = true; piv_col[pr] = pc;
+        const double inv = 1. / A[pr][pc];
+        for (int i = 0; i < 8; i++) {
+            if (i == pr) continue;
+            const double m = A[i][pc] * inv;
+            for (int j = 0; j < 9; j++)
+                if (!col_used[j]) A[i][j] = A[i][j] - m * A[pr][j];
         }
     }
-    double y[9];
-    y[8] = 1.;
-    for (int k = 7; k >= 0; k--) {
-        double acc = 0.;
-        for (int j = k + 1; j < 9; j++) acc = acc + A[k][j] * y[j];
-        y[k] = -acc / A[k][k];
-    }
-    for (int j = 0; j < 9; j++) f[col_of[j]] = y[j];
+    int free_col = 0;
+    for (int j = 0; j < 9; j++) if (!col_used[j]) free_col = j;
+    for (int i = 0; i < 8; i++) f[piv_col[i]] = -A[i][free_col] / A[i][piv_col[i]];
+    f[free_col] = 1.;
     return true;
 }
 
