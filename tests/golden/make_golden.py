@@ -1,4 +1,4 @@
-"""Generates tests/golden/frontend_golden.npz from the CPU oracle (tests/oracle_lib.py).
+"""Generates tests/golden/frontend_golden.npz and tests/golden/outlier_golden.npz from the CPU oracle (tests/oracle_lib.py).
 
 The reference cannot be built here (it needs OpenCV 3, Eigen and Boost) and holds no test vectors, so these vectors pin
 the oracle's own output: they catch drift of the oracle and give the GPU tests fixed expected values that do not
@@ -48,7 +48,29 @@ def build():
     return out
 
 
+def build_outlier():
+    """Two-view correspondences (Brown-distorted pinhole cameras, 25 % random matches, some points already lost by LK)
+    and the final mask of the seeded fundamental-matrix RANSAC."""
+    import synth
+    c0 = np.array([458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
+    c1 = np.array([457.587, 456.134, 379.999, 255.238, -0.28368365, 0.07451284, -0.00010473, -3.55590700e-05])
+    prev, nxt, is_out = synth.two_view_matches(160, 40, c0, seed=77)
+    status = np.ones(160, dtype=np.uint8)
+    status[::11] = 0
+    out = {"calib_prev": c0, "calib_next": c1, "prev_xy": prev, "next_xy": nxt, "status_in": status, "is_outlier": is_out,
+           "hypotheses": np.int32(192), "seed": np.uint32(20240229)}
+    st, h, F = O.reject_outliers(prev, nxt, status, c0, c1, hypotheses=192, seed=20240229)
+    out["status_out"], out["winner"], out["F"] = st, np.int32(h), F
+    return out
+
+
 if __name__ == "__main__":
+    extra = build_outlier()
+    path = os.path.join(HERE, "outlier_golden.npz")
+    np.savez_compressed(path, **extra)
+    print(path, os.path.getsize(path), "bytes;", int(extra["status_out"].sum()), "of", len(extra["status_out"]), "kept, model", int(extra["winner"]))
+    if "--outlier-only" in sys.argv:
+        sys.exit(0)
     data = build()
     path = os.path.join(HERE, "frontend_golden.npz")
     np.savez_compressed(path, **data)

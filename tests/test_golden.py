@@ -12,6 +12,7 @@ import oracle_lib as O
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_golden.npz"))
 WIN, MAX_LEVEL, LEVELS = int(G["win"]), int(G["max_level"]), int(G["levels"])
 FAST_KEY = "fast_grid_4x3_need120_thr12"
+R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "outlier_golden.npz"))
 
 
 def test_oracle_reproduces_golden_vectors():
@@ -32,6 +33,19 @@ def test_oracle_reproduces_golden_vectors():
     assert used == int(G["gyro_used"]) and np.allclose(R, G["gyro_R"], atol=1e-7)
     assert np.allclose(O.homography(G["gyro_K4"], R), G["gyro_H"], atol=1e-5)
     assert np.allclose(O.predict_flow(G["gyro_K4"], R, G["lk_prev_xy"]), G["gyro_pred"], atol=1e-3)
+
+
+def test_oracle_reproduces_outlier_golden_vectors():
+    st, h, F = O.reject_outliers(R["prev_xy"], R["next_xy"], R["status_in"], R["calib_prev"], R["calib_next"],
+                                 hypotheses=int(R["hypotheses"]), seed=int(R["seed"]))
+    assert np.array_equal(st, R["status_out"]) and h == int(R["winner"]) and np.array_equal(F, R["F"])
+
+
+def test_outlier_golden_vectors_are_sane():
+    """Independent of any implementation: most true matches kept, nearly all random ones dropped, lost points stay lost."""
+    keep, bad, was = R["status_out"] == 1, R["is_outlier"], R["status_in"] == 1
+    assert not keep[~was].any()
+    assert keep[~bad & was].mean() >= 0.9 and keep[bad].mean() <= 0.15
 
 
 def test_golden_vectors_are_sane():
@@ -70,3 +84,12 @@ def test_device_matches_golden_vectors():
         H = ctx.homography(G["gyro_K4"], G["gyro_R"])
         assert np.allclose(H, G["gyro_H"], atol=1e-5)
         assert np.abs(ctx.predict_flow(H, G["lk_prev_xy"]) - G["gyro_pred"]).max() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_device_matches_outlier_golden_vectors():
+    from feature_tracker_amd import device as D
+    with D.DeviceContext(64, 64, max_levels=1, n_streams=1, n_slots=2, max_points=512, max_grid_cells=4, max_per_cell=4) as ctx:
+        st = ctx.reject_outliers([dict(prev_xy=R["prev_xy"], next_xy=R["next_xy"], status=R["status_in"], calib_prev=R["calib_prev"],
+                                       calib_next=R["calib_next"])], hypotheses=int(R["hypotheses"]), seed=int(R["seed"]))[0]
+    assert np.array_equal(st, R["status_out"])
