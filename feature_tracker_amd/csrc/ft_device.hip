@@ -19,6 +19,7 @@
 #include "ft_kernels_lk.hpp"
 #include "ft_kernels_outlier.hpp"
 #include "ft_kernels_pyramid.hpp"
+#include "ft_kernels_stereo.hpp"
 
 using namespace ftd;
 
@@ -576,14 +577,15 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     }
 
     size_t total = 0;
-    bool want_iters = false;
+    bool want_iters = false, stereo = false;
     for (int j = 0; j < n_jobs; j++) {
         const ft_lk_job& J = jobs[j];
         if (J.n < 0) return FT_E_INVALID;
         if (J.n > 0 && (!J.prev_xy || !J.next_xy || !J.status || !J.err)) return FT_E_INVALID;
-        if (reject && J.n > 0 && (!J.calib_prev || !J.calib_next)) return FT_E_INVALID;
+        if ((reject || J.stereo_Rt) && J.n > 0 && (!J.calib_prev || !J.calib_next)) return FT_E_INVALID;
         total += (size_t)J.n;
         if (J.iters) want_iters = true;
+        if (J.stereo_Rt && J.n > 0) stereo = true;
     }
     if (c->profile) want_iters = true;
     if (total > (size_t)c->lim.max_points) return FT_E_LIMIT;
@@ -592,9 +594,10 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     // pack the input block
     const size_t N = total;
     uint8_t* hb = c->lk_in_host;
-    const size_t off_ptjob = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256);
-    const size_t off_prev = off_ptjob + align_up(2 * (size_t)c->lim.max_points, 256);
-    const size_t off_next = off_prev + align_up(8 * (size_t)c->lim.max_points, 256);
+    // laid out for this batch's sizes, so that the fetch moves no unused bytes
+    const size_t off_ptjob = align_up(sizeof(LKJobDev) * (size_t)n_jobs, 256);
+    const size_t off_prev = off_ptjob + align_up(2 * N, 256);
+    const size_t off_next = off_prev + align_up(8 * N, 256);
     LKJobDev* dj = reinterpret_cast<LKJobDev*>(hb);
     uint16_t* ptjob = reinterpret_cast<uint16_t*>(hb + off_ptjob);
     float* pxy = reinterpret_cast<float*>(hb + off_prev);
@@ -613,11 +616,13 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         if (max_level_all < 0) max_level_all = ml;
         else if (ml != max_level_all) return FT_E_INVALID;   // one batch, one pyramid depth
         dj[j].img_prev = sp; dj[j].img_next = sn; dj[j].w0 = P.w; dj[j].h0 = P.h;
-        dj[j].use_H = J.H ? 1 : 0;
+        dj[j].use_H = (J.H && !J.stereo_Rt) ? 1 : 0;
         if (J.H) memcpy(dj[j].H, J.H, sizeof(float) * 9); else memset(dj[j].H, 0, sizeof(float) * 9);
         dj[j].first = (int)off; dj[j].count = J.n;
-        if (reject && J.n > 0) { memcpy(dj[j].calib, J.calib_prev, sizeof(double) * 8); memcpy(dj[j].calib + 8, J.calib_next, sizeof(double) * 8); }
+        if ((reject || J.stereo_Rt) && J.n > 0) { memcpy(dj[j].calib, J.calib_prev, sizeof(double) * 8); memcpy(dj[j].calib + 8, J.calib_next, sizeof(double) * 8); }
         else memset(dj[j].calib, 0, sizeof(dj[j].calib));
+        dj[j].use_stereo = (J.stereo_Rt && J.n > 0) ? 1 : 0; dj[j].pad_ = 0;
+        if (dj[j].use_stereo) memcpy(dj[j].stereo, J.stereo_Rt, sizeof(double) * 12); else memset(dj[j].stereo, 0, sizeof(dj[j].stereo));
         for (int i = 0; i < J.n; i++) ptjob[off + i] = (uint16_t)j;
         if (J.n) {
             memcpy(pxy + 2 * off, J.prev_xy, 8 * (size_t)J.n);
@@ -642,8 +647,16 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.guess_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_next);
     // Without a backward pass (which reads the forward results on the device) and without iteration counters, lane 0
     // of every wave writes its 13 result bytes straight into the pinned host block: no copy command to enqueue.
-    const bool direct_out = !fb && !want_iters && !reject;
+    const bool direct_out = !fb && !want_iters && !reject && !stereo;
     uint8_t* ob = direct_out ? c->lk_out_host_dev : c->lk_out_dev;
+    StereoArgs sa;
+    if (stereo) {   // guesses of the stereo jobs from the extrinsic rotation, written over the fetched guess block
+        sa.jobs = a.jobs; sa.pt_job = a.pt_job; sa.prev_xy = a.prev_xy;
+        sa.next_xy = reinterpret_cast<float*>(c->lk_in_dev + off_next);
+        sa.err = nullptr; sa.status = nullptr; sa.out_xy = nullptr; sa.out_err = nullptr; sa.out_status = nullptr;
+        sa.total = (int)N; sa.emit = 0; sa.threshold = prm->stereo_threshold;
+        hipLaunchKernelGGL(stereo_seed_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->q, sa);
+    }
     a.next_xy = reinterpret_cast<float*>(ob);
     a.err = reinterpret_cast<float*>(ob + 8 * N);
     a.status = ob + 12 * N;
@@ -676,6 +689,17 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
 
+    if (stereo) {   // bounds + epipolar test of the stereo jobs; without a rejection pass after it, it also emits the results
+        sa.next_xy = a.next_xy; sa.err = a.err; sa.status = a.status;
+        sa.out_xy = reinterpret_cast<float*>(c->lk_out_host_dev);
+        sa.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);
+        sa.out_status = c->lk_out_host_dev + 12 * N;
+        sa.emit = reject ? 0 : 1;
+        hipLaunchKernelGGL(stereo_check_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->q, sa);
+        FT_HIP(c, hipGetLastError());
+        if (!reject && want_iters)
+            FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
+    }
     if (reject) {
         // final mask on the device; the kernel also moves positions, residuals and status into the pinned host block
         OutlierArgs o;
@@ -691,7 +715,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         FT_HIP(c, hipGetLastError());
         if (want_iters)
             FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
-    } else if (!direct_out) {
+    } else if (!direct_out && !stereo) {
         const size_t out_bytes = align_up(13 * N, 16) + (want_iters ? sizeof(int) * N * nlev : 0);
         FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, c->q));
     }
@@ -720,9 +744,9 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
     }
     // same input block as a tracking batch; the per-point job index is not needed here, its place holds the status bytes
     uint8_t* hb = c->lk_in_host;
-    const size_t off_status = align_up(sizeof(LKJobDev) * FT_MAX_BATCH, 256);
-    const size_t off_prev = off_status + align_up(2 * (size_t)c->lim.max_points, 256);
-    const size_t off_next = off_prev + align_up(8 * (size_t)c->lim.max_points, 256);
+    const size_t off_status = align_up(sizeof(LKJobDev) * (size_t)n_sets, 256);
+    const size_t off_prev = off_status + align_up(2 * N, 256);
+    const size_t off_next = off_prev + align_up(8 * N, 256);
     LKJobDev* dj = reinterpret_cast<LKJobDev*>(hb);
     std::vector<ft_lk_job> deliver((size_t)n_sets);
     size_t off = 0;

@@ -28,7 +28,10 @@ struct LKJobDev {
     int use_H;                // 1: initial guess = pi(H * [prev;1])
     float H[9];
     int first, count;         // this job's points in the batch arrays
-    double calib[16];         // fx fy cx cy k1 k2 p1 p2 of the template camera, then of the target camera (outlier rejection)
+    double calib[16];         // fx fy cx cy k1 k2 p1 p2 of the template camera, then of the target camera (outlier rejection, stereo)
+    double stereo[12];        // R_cam0_cam1 (row-major), t_cam0_cam1
+    int use_stereo;           // 1: stereo match (seed from the extrinsic rotation, epipolar check after tracking)
+    int pad_;
 };
 
 struct LKArgs {
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             use_init = true;
         } else {
             gx0 = a.guess_xy[2 * pt]; gy0 = a.guess_xy[2 * pt + 1];
-            use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0;
+            use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0 || job->use_stereo != 0;   // stereo guesses were written on the device
         }
     } else {
         tx = a.next_xy[2 * pt]; ty = a.next_xy[2 * pt + 1];

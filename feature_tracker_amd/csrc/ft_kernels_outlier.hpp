@@ -42,10 +42,10 @@ __device__ __forceinline__ uint32_t ro_mix32(uint32_t x) {
 }
 
 // TrackBase::undistort_point: remove K, five fixed-point iterations of the inverse radial-tangential model
-__device__ __forceinline__ float2 ro_undistort(float u, float v, const double* c) {
+__device__ __forceinline__ void ro_undistort_d(float u, float v, const double* c, double& x, double& y) {
     const double ifx = 1. / c[0], ify = 1. / c[1];
     const double x0 = ((double)u - c[2]) * ifx, y0 = ((double)v - c[3]) * ify;
-    double x = x0, y = y0;
+    x = x0; y = y0;
     if (c[4] != 0. || c[5] != 0. || c[6] != 0. || c[7] != 0.) {
         for (int it = 0; it < 5; it++) {
             const double r2 = x * x + y * y;
@@ -56,6 +56,11 @@ __device__ __forceinline__ float2 ro_undistort(float u, float v, const double* c
             y = (y0 - dy) * icdist;
         }
     }
+}
+
+__device__ __forceinline__ float2 ro_undistort(float u, float v, const double* c) {
+    double x, y;
+    ro_undistort_d(u, v, c, x, y);
     return make_float2((float)x, (float)y);
 }
 

@@ -34,13 +34,14 @@ class ft_limits(C.Structure):
 class ft_lk_params(C.Structure):
     _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("max_iter", C.c_int),
                 ("eps", C.c_double), ("min_eig", C.c_double), ("flags", C.c_int), ("fb_thresh", C.c_float),
-                ("ransac_hypotheses", C.c_int), ("ransac_seed", C.c_uint)]
+                ("ransac_hypotheses", C.c_int), ("ransac_seed", C.c_uint), ("stereo_threshold", C.c_double)]
 
 
 class ft_lk_job(C.Structure):
     _fields_ = [("stream_prev", C.c_int), ("slot_prev", C.c_int), ("stream_next", C.c_int), ("slot_next", C.c_int),
                 ("n", C.c_int), ("prev_xy", C.c_void_p), ("next_xy", C.c_void_p), ("status", C.c_void_p),
-                ("err", C.c_void_p), ("H", C.c_void_p), ("iters", C.c_void_p), ("calib_prev", C.c_void_p), ("calib_next", C.c_void_p)]
+                ("err", C.c_void_p), ("H", C.c_void_p), ("iters", C.c_void_p), ("calib_prev", C.c_void_p), ("calib_next", C.c_void_p),
+                ("stereo_Rt", C.c_void_p)]
 
 
 class ft_match_set(C.Structure):
@@ -149,15 +150,16 @@ class LKParams:
     src/track/TrackKLT.cpp:305,:401)."""
 
     def __init__(self, win=15, max_level=3, max_iter=15, eps=0.01, min_eig=1e-4, flags=FT_LK_USE_INITIAL_FLOW, fb_thresh=1.0,
-                 ransac_hypotheses=0, ransac_seed=0):
+                 ransac_hypotheses=0, ransac_seed=0, stereo_threshold=3.0):
         self.win_w, self.win_h = (win, win) if np.isscalar(win) else win
         self.max_level, self.max_iter, self.eps, self.min_eig = max_level, max_iter, eps, min_eig
         self.flags, self.fb_thresh = flags, fb_thresh
         self.ransac_hypotheses, self.ransac_seed = ransac_hypotheses, ransac_seed
+        self.stereo_threshold = stereo_threshold
 
     def c_struct(self):
         return ft_lk_params(self.win_w, self.win_h, self.max_level, self.max_iter, self.eps, self.min_eig, self.flags, self.fb_thresh,
-                            self.ransac_hypotheses, self.ransac_seed)
+                            self.ransac_hypotheses, self.ransac_seed, self.stereo_threshold)
 
 
 class DeviceContext:
@@ -259,7 +261,8 @@ class DeviceContext:
 
     # -- LK --
     def lk_track(self, jobs, params, want_iters=False, sync=True):
-        """jobs: list of dicts {prev:(stream,slot), next:(stream,slot), prev_xy:(n,2) float32, guess:(n,2)|None, H:(3,3)|None}.
+        """jobs: list of dicts {prev:(stream,slot), next:(stream,slot), prev_xy:(n,2) float32, guess:(n,2)|None, H:(3,3)|None,
+        calib_prev / calib_next:(8,)|None, stereo_Rt:(12,)|None}.
         Returns a list of (next_xy, status, err[, iters]) per job (filled after the sync)."""
         cj = (ft_lk_job * len(jobs))()
         outs = []
@@ -276,11 +279,12 @@ class DeviceContext:
             H = None if j.get("H") is None else np.ascontiguousarray(j["H"], dtype=np.float32).reshape(9)
             c0 = None if j.get("calib_prev") is None else np.ascontiguousarray(j["calib_prev"], dtype=np.float64).reshape(8)
             c1 = c0 if j.get("calib_next") is None else np.ascontiguousarray(j["calib_next"], dtype=np.float64).reshape(8)
+            rt = None if j.get("stereo_Rt") is None else np.ascontiguousarray(j["stereo_Rt"], dtype=np.float64).reshape(12)
             cj[i] = ft_lk_job(j["prev"][0], j["prev"][1], j["next"][0], j["next"][1], n, prev_xy.ctypes.data, nxt.ctypes.data,
                               st.ctypes.data, er.ctypes.data, None if H is None else H.ctypes.data,
                               None if it is None else it.ctypes.data, None if c0 is None else c0.ctypes.data,
-                              None if c1 is None else c1.ctypes.data)
-            keep += [prev_xy, nxt, st, er, it, H, c0, c1]
+                              None if c1 is None else c1.ctypes.data, None if rt is None else rt.ctypes.data)
+            keep += [prev_xy, nxt, st, er, it, H, c0, c1, rt]
             outs.append((nxt, st, er, it) if want_iters else (nxt, st, er))
         p = params.c_struct()
         fn = self.lib.ft_lk_track if sync else self.lib.ft_lk_track_async

@@ -36,6 +36,11 @@ struct FeatureTrackerOptions {
     // because the sampling is this build's own and cannot reproduce OpenCV's inlier sets)
     bool reject_outliers = false;
     int ransac_hypotheses = 256;
+    // left -> right association of new features as TrackMsckfVio::stereoMatch does it (src/track/TrackMsckfVio.cpp:218-301):
+    // guess from the stereo extrinsics instead of "same pixel" (the TODO at src/track/TrackKLT.cpp:290-295), then the
+    // known-essential-matrix test.  Needs both cameras' extrinsics.
+    bool stereo_extrinsic_seed = false;
+    double stereo_threshold = 3.0;   // px, src/track/TrackMsckfVio.h:217
 
     void print_trackers() const {
         printf("FEATURE TRACKING PARAMETERS:\n");

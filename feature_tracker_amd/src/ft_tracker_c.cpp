@@ -32,6 +32,7 @@ FeatureTrackerOptions to_options(const ftk_options& o) {
     r.lk_eps = o.lk_eps; r.lk_min_eig = o.lk_min_eig; r.use_gyro_seed = o.use_gyro_seed != 0;
     r.forward_backward = o.forward_backward != 0; r.fb_thresh = o.fb_thresh; r.speculative_detect = o.speculative_detect != 0;
     r.reject_outliers = o.reject_outliers != 0; if (o.ransac_hypotheses > 0) r.ransac_hypotheses = o.ransac_hypotheses;
+    r.stereo_extrinsic_seed = o.stereo_extrinsic_seed != 0; r.stereo_threshold = o.stereo_threshold;
     return r;
 }
 
@@ -323,6 +324,7 @@ void ftk_default_options(ftk_options* o) {
     o->lk_eps = d.lk_eps; o->lk_min_eig = d.lk_min_eig; o->use_gyro_seed = d.use_gyro_seed; o->forward_backward = d.forward_backward;
     o->fb_thresh = d.fb_thresh; o->speculative_detect = d.speculative_detect;
     o->reject_outliers = d.reject_outliers; o->ransac_hypotheses = d.ransac_hypotheses;
+    o->stereo_extrinsic_seed = d.stereo_extrinsic_seed; o->stereo_threshold = d.stereo_threshold;
 }
 
 const char* ftk_backend_name(void) { return ftk_backend_label(); }

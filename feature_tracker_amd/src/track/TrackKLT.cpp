@@ -19,6 +19,7 @@ ft_lk_params TrackKLT::lk_params() const {
     p.fb_thresh = fb_thresh;
     p.ransac_hypotheses = ransac_hypotheses;     // TrackKLT.cpp:405-424
     p.ransac_seed = frames_fed;
+    p.stereo_threshold = stereo_threshold;
     return p;
 }
 
@@ -40,6 +41,20 @@ void TrackKLT::calib8_of(size_t cam_id, double* out8) const {
         out8[i] = k != camera_k.end() ? k->second[i] : ident[i];
         out8[4 + i] = d != camera_d.end() ? d->second[i] : 0.;
     }
+}
+
+bool TrackKLT::stereo_Rt_of(size_t cam0, size_t cam1, double* out) const {
+    const auto r0 = R_cam_imu.find(cam0), r1 = R_cam_imu.find(cam1);
+    const auto t0 = t_cam_imu.find(cam0), t1 = t_cam_imu.find(cam1);
+    if (r0 == R_cam_imu.end() || r1 == R_cam_imu.end() || t0 == t_cam_imu.end() || t1 == t_cam_imu.end()) return false;
+    const Mat3d& A = r0->second;
+    const Mat3d& B = r1->second;
+    // R_cam0_cam1 = R_cam_imu(0)^T R_cam_imu(1);  t_cam0_cam1 = R_cam_imu(1)^T (t_cam_imu(0) - t_cam_imu(1))
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) out[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+    const double d[3] = {t0->second[0] - t1->second[0], t0->second[1] - t1->second[1], t0->second[2] - t1->second[2]};
+    for (int r = 0; r < 3; r++) out[9 + r] = B[r] * d[0] + B[3 + r] * d[1] + B[6 + r] * d[2];
+    return true;
 }
 
 bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float* H) {
@@ -303,7 +318,8 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
 }
 
 void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
-                                        std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1) {
+                                        std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
+                                        size_t cam_id_left, size_t cam_id_right) {
     Occupancy grid0(img0.cols, img0.rows, min_px_dist), grid1(img1.cols, img1.rows, min_px_dist);
     filter_by_occupancy(grid0, pts0, ids0);
     filter_by_occupancy(grid1, pts1, ids1);
@@ -332,6 +348,12 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
             J.n = (int)n; J.prev_xy = p0.data(); J.next_xy = p1.data(); J.status = mask.data(); J.err = err.data();
             ft_lk_params prm = lk_params();
             prm.flags = FT_LK_USE_INITIAL_FLOW;   // the stereo association has no backward pass in the reference
+            // optional: guess from the stereo extrinsics and known-E test (TrackMsckfVio.cpp:218-301) instead of "same pixel"
+            double c0[8], c1[8], Rt[12];
+            if (stereo_extrinsic_seed && stereo_Rt_of(cam_id_left, cam_id_right, Rt)) {
+                calib8_of(cam_id_left, c0); calib8_of(cam_id_right, c1);
+                J.calib_prev = c0; J.calib_next = c1; J.stereo_Rt = Rt;
+            }
             const bool ok = be->lk_track_async(1, &J, &prm) == FT_OK && be->sync() == FT_OK;
             for (size_t i = 0; ok && i < n; i++) {
                 const Point2f a(p0[2 * i], p0[2 * i + 1]), b(p1[2 * i], p1[2 * i + 1]);
@@ -400,7 +422,7 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
 
     // first call, or tracking was lost: just extract (TrackKLT.cpp:63-72)
     if (ptsL.empty() || ptsR.empty() || cl.slot_last < 0 || cr.slot_last < 0) {
-        perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR);
+        perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right);
         roll();
         return;
     }
@@ -408,7 +430,7 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     // top the previous pair up (TrackKLT.cpp:76-78)
     const DeviceImage last_left{be, sl, cl.slot_last, cl.cols, cl.rows};
     const DeviceImage last_right{be, sr, cr.slot_last, cr.cols, cr.rows};
-    perform_detection_stereo(last_left, last_right, ptsL, ptsR, idsL, idsR);
+    perform_detection_stereo(last_left, last_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right);
 
     // temporal tracking of both cameras in one launch (TrackKLT.cpp:86-98)
     std::vector<uint8_t> mask_ll, mask_rr;

@@ -52,7 +52,7 @@ public:
           grid_y(o.grid_y), min_px_dist(o.min_px_dist), pyr_levels(o.pyr_levels), win_size(o.win_size), lk_max_iter(o.lk_max_iter),
           lk_eps(o.lk_eps), lk_min_eig(o.lk_min_eig), use_gyro_seed(o.use_gyro_seed), forward_backward(o.forward_backward),
           fb_thresh(o.fb_thresh), speculative_detect(o.speculative_detect), reject_outliers(o.reject_outliers),
-          ransac_hypotheses(o.ransac_hypotheses) {}
+          ransac_hypotheses(o.ransac_hypotheses), stereo_extrinsic_seed(o.stereo_extrinsic_seed), stereo_threshold(o.stereo_threshold) {}
 
     void feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) override;
 
@@ -121,7 +121,8 @@ public:
 protected:
     // src/track/TrackKLT.cpp:223-368
     void perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
-                                  std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1);
+                                  std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
+                                  size_t cam_id_left = 0, size_t cam_id_right = 1);
     // monocular top-off: occupancy filter, then new points from a ranked detection
     void perform_detection_monocular(int cols, int rows, const Detection& det, std::vector<KeyPoint>& pts0, std::vector<size_t>& ids0);
     // src/track/TrackKLT.cpp:371-432 for one or two (img0 -> img1) pairs in one launch
@@ -166,6 +167,9 @@ protected:
     bool gyro_homography(size_t cam_id, double t_last, double t_cur, float* H);
     // fx fy cx cy k1 k2 p1 p2 of a camera; an uncalibrated camera counts as the identity model
     void calib8_of(size_t cam_id, double* out8) const;
+    // R_cam0_cam1 (row-major) then t_cam0_cam1 from the two cameras' extrinsics (TrackMsckfVio.cpp:228-231); false
+    // if one of them was never set
+    bool stereo_Rt_of(size_t cam0, size_t cam1, double* out12) const;
 
     FrontendBackend* be;
     int stream0;
@@ -188,6 +192,8 @@ protected:
     bool speculative_detect = true;
     bool reject_outliers = false;
     int ransac_hypotheses = 256;
+    bool stereo_extrinsic_seed = false;
+    double stereo_threshold = 3.0;
     unsigned frames_fed = 0;   // seeds the outlier rejection's sample sequence: every frame draws other samples
     int slot_ring = 2;
     // per-tracker scratch reused every frame (no allocation in the steady state)

@@ -14,7 +14,8 @@ class ftk_options(C.Structure):
                 ("min_px_dist", C.c_int), ("pyr_levels", C.c_int), ("win_size", C.c_int), ("lk_max_iter", C.c_int),
                 ("lk_eps", C.c_double), ("lk_min_eig", C.c_double), ("use_gyro_seed", C.c_int), ("forward_backward", C.c_int),
                 ("fb_thresh", C.c_float), ("speculative_detect", C.c_int),
-                ("reject_outliers", C.c_int), ("ransac_hypotheses", C.c_int)]
+                ("reject_outliers", C.c_int), ("ransac_hypotheses", C.c_int),
+                ("stereo_extrinsic_seed", C.c_int), ("stereo_threshold", C.c_double)]
 
 
 SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "ftk_tracker_set_calibration",

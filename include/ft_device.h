@@ -73,6 +73,8 @@ typedef struct ft_lk_params {
     float fb_thresh;     /* px; only with FT_LK_FORWARD_BACKWARD */
     int ransac_hypotheses;    /* only with FT_LK_REJECT_OUTLIERS: models tried per job, 1..256 (0 = 256) */
     unsigned ransac_seed;     /* only with FT_LK_REJECT_OUTLIERS: seed of the sample sequence */
+    double stereo_threshold;  /* only for jobs with stereo_Rt: largest distance to the epipolar line, in pixels
+                                 (src/track/TrackMsckfVio.h:217 -> 3); <= 0 switches the check off (seed only) */
 } ft_lk_params;
 
 /* One LK job = one calcOpticalFlowPyrLK call of the reference (one image pair, n points). */
@@ -88,6 +90,13 @@ typedef struct ft_lk_job {
     int* iters;                   /* optional n*(max_level+1): Newton iterations per level, -1 = level skipped */
     const double* calib_prev;     /* with FT_LK_REJECT_OUTLIERS: fx fy cx cy k1 k2 p1 p2 of the template image's camera */
     const double* calib_next;     /* ... and of the target image's camera (the same pointer for temporal tracking) */
+    const double* stereo_Rt;      /* optional, 12 doubles: R_cam0_cam1 (row-major 3x3) then t_cam0_cam1, prev = cam0, next = cam1.
+                                     Makes the job a stereo match as TrackMsckfVio::stereoMatch does it
+                                     (src/track/TrackMsckfVio.cpp:218-301): the initial guess of every point is its
+                                     projection into cam1 under pure rotation (undistort with cam0, rotate, distort with
+                                     cam1; :238-249; next_xy is not read), and after LK a point is dropped if it left the
+                                     image (:259-268) or lies further than stereo_threshold pixels from its epipolar
+                                     line under E = [t]x R (:270-298).  Needs calib_prev / calib_next. */
 } ft_lk_job;
 
 /* One set of point correspondences for outlier rejection alone. */

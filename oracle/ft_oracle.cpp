@@ -652,11 +652,11 @@ inline uint32_t mix32(uint32_t x) {
 }
 
 // what TrackBase::undistort_point does (cv::undistortPoints for one point): remove K, five fixed-point iterations of
-// the inverse radial-tangential model, result rounded to float like cv::Point2f
-inline void undistort_to_float(float u, float v, const double* c, float& xn, float& yn) {
+// the inverse radial-tangential model
+inline void undistort_to_double(float u, float v, const double* c, double& x, double& y) {
     const double ifx = 1. / c[0], ify = 1. / c[1];
     const double x0 = ((double)u - c[2]) * ifx, y0 = ((double)v - c[3]) * ify;
-    double x = x0, y = y0;
+    x = x0; y = y0;
     if (c[4] != 0. || c[5] != 0. || c[6] != 0. || c[7] != 0.) {
         for (int it = 0; it < 5; it++) {
             const double r2 = x * x + y * y;
@@ -667,6 +667,12 @@ inline void undistort_to_float(float u, float v, const double* c, float& xn, flo
             y = (y0 - dy) * icdist;
         }
     }
+}
+
+// ... with the result rounded to float like cv::Point2f
+inline void undistort_to_float(float u, float v, const double* c, float& xn, float& yn) {
+    double x, y;
+    undistort_to_double(u, v, c, x, y);
     xn = (float)x; yn = (float)y;
 }
 
@@ -769,6 +775,50 @@ int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* sta
         if (!is_inlier(best_F, m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3], thr2)) status[i] = 0;
     if (F_out) for (int q = 0; q < 9; q++) F_out[q] = best_F[q];
     return best_h;
+}
+
+void fto_stereo_seed(const float* cam0_xy, int n, const double* c0, const double* c1, const double* Rt, float* cam1_xy) {
+    for (int i = 0; i < n; i++) {
+        double x, y;
+        undistort_to_double(cam0_xy[2 * i], cam0_xy[2 * i + 1], c0, x, y);
+        const double X = Rt[0] * x + Rt[1] * y + Rt[2], Y = Rt[3] * x + Rt[4] * y + Rt[5], W = Rt[6] * x + Rt[7] * y + Rt[8];
+        const double iw = 1. / W;
+        // cv::Point2f between the two calls.  Through volatile: g++ 11 -O3 otherwise drops this rounding when it
+        // vectorizes the loop.
+        volatile float xf = (float)(X * iw), yf = (float)(Y * iw);
+        const double xr = (double)xf, yr = (double)yf;
+        const double r2 = xr * xr + yr * yr, r4 = r2 * r2;
+        const double cdist = 1. + c1[4] * r2 + c1[5] * r4;
+        const double a1 = 2. * xr * yr, a2 = r2 + 2. * xr * xr, a3 = r2 + 2. * yr * yr;
+        const double xd = xr * cdist + c1[6] * a1 + c1[7] * a2;
+        const double yd = yr * cdist + c1[6] * a3 + c1[7] * a1;
+        cam1_xy[2 * i] = (float)(xd * c1[0] + c1[2]);
+        cam1_xy[2 * i + 1] = (float)(yd * c1[1] + c1[3]);
+    }
+}
+
+void fto_stereo_check(const float* cam0_xy, const float* cam1_xy, uint8_t* status, int n, const double* c0, const double* c1,
+                      const double* Rt, int w, int h, double threshold) {
+    const double* R = Rt;
+    const double* t = Rt + 9;
+    // E = [t]x R
+    const double E[9] = {-t[2] * R[3] + t[1] * R[6], -t[2] * R[4] + t[1] * R[7], -t[2] * R[5] + t[1] * R[8],
+                         t[2] * R[0] - t[0] * R[6],  t[2] * R[1] - t[0] * R[7],  t[2] * R[2] - t[0] * R[8],
+                         -t[1] * R[0] + t[0] * R[3], -t[1] * R[1] + t[0] * R[4], -t[1] * R[2] + t[0] * R[5]};
+    const double unit = 4.0 / (c0[0] + c0[1] + c1[0] + c1[1]);
+    for (int i = 0; i < n; i++) {
+        if (!status[i]) continue;
+        const float nx = cam1_xy[2 * i], ny = cam1_xy[2 * i + 1];
+        if (ny < 0.f || ny > (float)(h - 1) || nx < 0.f || nx > (float)(w - 1)) { status[i] = 0; continue; }
+        if (!(threshold > 0.)) continue;
+        float fx0, fy0, fx1, fy1;
+        undistort_to_float(cam0_xy[2 * i], cam0_xy[2 * i + 1], c0, fx0, fy0);
+        undistort_to_float(nx, ny, c1, fx1, fy1);
+        const double x0 = fx0, y0 = fy0, x1 = fx1, y1 = fy1;
+        const double l0 = E[0] * x0 + E[1] * y0 + E[2], l1 = E[3] * x0 + E[4] * y0 + E[5], l2 = E[6] * x0 + E[7] * y0 + E[8];
+        const double error = std::fabs(x1 * l0 + y1 * l1 + l2) / std::sqrt(l0 * l0 + l1 * l1);
+        if (error > threshold * unit) status[i] = 0;
+    }
 }
 
 }  // extern "C"

@@ -106,8 +106,8 @@ void fto_homography(const float* K4, const float* R_p_c, float* H);
  *   - both point sets are undistorted like TrackBase::undistort_point (src/track/TrackBase.h:289-332) and rounded to
  *     float, calib8 = fx, fy, cx, cy, k1, k2, p1, p2;
  *   - `hypotheses` models (0 = 256) are fitted, model h from the 8 distinct pairs drawn by a counter-based hash of
- *     (seed, h, draw number); the null vector of the 8x9 epipolar system comes from Gaussian elimination with complete
- *     pivoting in double precision (a sample whose pivot falls below 1e-12 is skipped);
+ *     (seed, h, draw number); the null vector of the 8x9 epipolar system comes from Gauss-Jordan elimination with complete
+ *     pivoting in double precision (ties: lowest row, then lowest column; a sample whose pivot falls below 1e-12 is skipped);
  *   - a pair is an inlier of a model if (float)max(d1^2*s1, d2^2*s2) <= thr^2, the symmetric epipolar distance of
  *     OpenCV's estimator, thr = 1 / max(fx, fy of both cameras);
  *   - the model with the most inliers wins, the lower index on ties; status[i] &= inlier[i]; no model with at least
@@ -115,6 +115,18 @@ void fto_homography(const float* K4, const float* R_p_c, float* H);
  * All n pairs take part, tracked or not, as in the reference.  Returns the winning model index or -1. */
 int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* status, int n, const double* calib8_prev,
                         const double* calib8_next, int hypotheses, uint32_t seed, double* F_out);
+
+/* Stereo matching geometry of TrackMsckfVio::stereoMatch (src/track/TrackMsckfVio.cpp:218-301), the parts around
+ * its LK call.  Rt12 = R_cam0_cam1 (row-major 3x3) followed by t_cam0_cam1.
+ * fto_stereo_seed: guess of every cam0 point in cam1 under the rotation alone, i.e.
+ *   cv::undistortPoints(K0, D0, R_cam0_cam1) -> Point2f -> cv::projectPoints(K1, D1) (:238-249).
+ * fto_stereo_check: status[i] = 0 for tracked points outside [0, w-1] x [0, h-1] (:259-268) and, if threshold > 0, for
+ *   points whose distance to the epipolar line of E = [t]x R exceeds threshold * 4 / (fx0 + fy0 + fx1 + fy1) in
+ *   normalized coordinates (:270-298). */
+void fto_stereo_seed(const float* cam0_xy, int n, const double* calib8_cam0, const double* calib8_cam1, const double* Rt12,
+                     float* cam1_xy);
+void fto_stereo_check(const float* cam0_xy, const float* cam1_xy, uint8_t* status, int n, const double* calib8_cam0,
+                      const double* calib8_cam1, const double* Rt12, int w, int h, double threshold);
 
 #ifdef __cplusplus
 }

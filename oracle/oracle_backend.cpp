@@ -87,7 +87,11 @@ public:
             const ft_lk_job& J = jobs[j];
             if (J.n <= 0) return;
             fto_lk_params pj = p;
-            if (J.H) {   // gyro seed: initial guess = pi(H * [prev;1])
+            const bool stereo = J.stereo_Rt && J.calib_prev && J.calib_next;
+            if (stereo) {   // stereo seed from the extrinsic rotation
+                fto_stereo_seed(J.prev_xy, J.n, J.calib_prev, J.calib_next, J.stereo_Rt, J.next_xy);
+                pj.flags |= FTO_LK_USE_INITIAL_FLOW;
+            } else if (J.H) {   // gyro seed: initial guess = pi(H * [prev;1])
                 for (int i = 0; i < J.n; i++) {
                     const float x = J.prev_xy[2 * i], y = J.prev_xy[2 * i + 1];
                     const float p0 = J.H[0] * x + J.H[1] * y + J.H[2];
@@ -99,6 +103,9 @@ public:
             }
             fto_lk_track(at(J.stream_prev, J.slot_prev)->pyr, at(J.stream_next, J.slot_next)->pyr, J.prev_xy, J.next_xy, J.status,
                          J.err, J.n, &pj, outer ? 1 : g_threads, J.iters);
+            if (stereo)
+                fto_stereo_check(J.prev_xy, J.next_xy, J.status, J.n, J.calib_prev, J.calib_next, J.stereo_Rt, at(J.stream_prev, J.slot_prev)->w,
+                                 at(J.stream_prev, J.slot_prev)->h, prm->stereo_threshold);
             if ((prm->flags & FT_LK_REJECT_OUTLIERS) && J.calib_prev && J.calib_next)
                 fto_reject_outliers(J.prev_xy, J.next_xy, J.status, J.n, J.calib_prev, J.calib_next, prm->ransac_hypotheses, prm->ransac_seed, nullptr);
         });

@@ -191,3 +191,30 @@ def reject_outliers(prev_xy, next_xy, status, calib8_prev, calib8_next=None, hyp
     h = L.fto_reject_outliers(prev_xy.ctypes.data, next_xy.ctypes.data, st.ctypes.data, prev_xy.shape[0], c0.ctypes.data, c1.ctypes.data,
                               hypotheses, seed, F.ctypes.data)
     return st, h, F.reshape(3, 3)
+
+
+def stereo_seed(cam0_xy, calib8_cam0, calib8_cam1, Rt12):
+    """Guesses in cam1 of cam0 points under the extrinsic rotation (undistort, rotate, distort)."""
+    xy = np.ascontiguousarray(cam0_xy, dtype=np.float32).reshape(-1, 2)
+    c0, c1 = np.ascontiguousarray(calib8_cam0, dtype=np.float64), np.ascontiguousarray(calib8_cam1, dtype=np.float64)
+    rt = np.ascontiguousarray(Rt12, dtype=np.float64).reshape(12)
+    out = np.zeros_like(xy)
+    L = lib()
+    L.fto_stereo_seed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fto_stereo_seed.restype = None
+    L.fto_stereo_seed(xy.ctypes.data, xy.shape[0], c0.ctypes.data, c1.ctypes.data, rt.ctypes.data, out.ctypes.data)
+    return out
+
+
+def stereo_check(cam0_xy, cam1_xy, status, calib8_cam0, calib8_cam1, Rt12, w, h, threshold=3.0):
+    """status with the out-of-image and off-epipolar-line points cleared."""
+    a = np.ascontiguousarray(cam0_xy, dtype=np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(cam1_xy, dtype=np.float32).reshape(-1, 2)
+    st = np.ascontiguousarray(status, dtype=np.uint8).copy()
+    c0, c1 = np.ascontiguousarray(calib8_cam0, dtype=np.float64), np.ascontiguousarray(calib8_cam1, dtype=np.float64)
+    rt = np.ascontiguousarray(Rt12, dtype=np.float64).reshape(12)
+    L = lib()
+    L.fto_stereo_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
+    L.fto_stereo_check.restype = None
+    L.fto_stereo_check(a.ctypes.data, b.ctypes.data, st.ctypes.data, a.shape[0], c0.ctypes.data, c1.ctypes.data, rt.ctypes.data, w, h, threshold)
+    return st

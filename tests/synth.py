@@ -108,3 +108,33 @@ def with_moving_patches(frames, size=96, seed=0, velocities=((4.0, 0.0), (0.0, -
             x, y = min(max(x, 0), w - size), min(max(y, 0), h - size)
             out[i, y:y + size, x:x + size] = tex
     return out
+
+
+def rotation_xyz(rot):
+    rx, ry, rz = rot
+    Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+    Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+    Rz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def project_brown(P, calib8):
+    """Pinhole projection with radial-tangential distortion of 3-D points (n, 3), in double."""
+    fx, fy, cx, cy, k1, k2, p1, p2 = calib8
+    x, y = P[:, 0] / P[:, 2], P[:, 1] / P[:, 2]
+    r2 = x * x + y * y
+    cd = 1 + k1 * r2 + k2 * r2 * r2
+    xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([fx * xd + cx, fy * yd + cy], axis=1)
+
+
+def stereo_views(n, calib8_cam0, calib8_cam1, rot=(0.004, -0.01, 0.006), t=(-0.11, 0.002, 0.001), seed=0, depth=(2.0, 12.0)):
+    """n random 3-D points seen by a stereo rig, X_cam1 = R X_cam0 + t.  Returns (cam0_xy, cam1_xy, Rt12, depth)."""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(depth[0], depth[1], n)
+    X = np.stack([rng.uniform(-0.6, 0.6, n) * z, rng.uniform(-0.4, 0.4, n) * z, z], axis=1)
+    R = rotation_xyz(rot)
+    a = project_brown(X, calib8_cam0)
+    b = project_brown(X @ R.T + np.asarray(t), calib8_cam1)
+    return a.astype(np.float32), b.astype(np.float32), np.concatenate([R.reshape(9), np.asarray(t, dtype=np.float64)]), z

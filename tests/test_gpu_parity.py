@@ -292,6 +292,67 @@ def test_lk_with_outlier_rejection_equals_lk_then_oracle_rejection(dev):
     assert np.array_equal(strict[1], want)
 
 
+STEREO_RIGS = [
+    # undistorted twin cameras, pure sideways baseline: the epipolar lines are the image rows
+    ((460.0, 460.0, 320.0, 200.0, 0, 0, 0, 0), (460.0, 460.0, 320.0, 200.0, 0, 0, 0, 0), (0, 0, 0), (-0.11, 0, 0)),
+    # distorted, slightly different cameras, slightly rotated rig
+    ((458.654, 457.296, 317.2, 198.4, -0.2834, 0.0740, 1.9e-4, 1.8e-5), (457.587, 456.134, 322.0, 203.2, -0.2837, 0.0745, -1.0e-4, -3.6e-5),
+     (0.002, -0.004, 0.003), (-0.11, 0.001, 0.0005)),
+]
+
+
+@pytest.mark.parametrize("c0,c1,rot,t", STEREO_RIGS)
+@pytest.mark.parametrize("threshold", [3.0, 0.5, 0.0])
+def test_lk_stereo_job_equals_oracle_seed_track_check(dev, c0, c1, rot, t, threshold):
+    """A job with stereo_Rt = seed from the extrinsic rotation, LK, frame + epipolar test, all on the device; against the
+    CPU checker's three steps.  Right image = left image displaced along the rows (a fronto-parallel plane)."""
+    w, h = 640, 400
+    left, right = synth.shifted_pair(w, h, dx=-7, dy=0, seed=90)
+    pts = synth.random_points(w, h, 400, seed=91, border=-6)
+    Rt = np.concatenate([synth.rotation_xyz(rot).reshape(9), np.asarray(t, dtype=np.float64)])
+    pl, pr = O.Pyramid(left, 21, 3), O.Pyramid(right, 21, 3)
+    guess = O.stereo_seed(pts, c0, c1, Rt)
+    r_xy, r_st, r_err = O.lk_track(pl, pr, pts, guess=guess, win=21, max_level=3)
+    want = O.stereo_check(pts, r_xy, r_st, c0, c1, Rt, w, h, threshold)
+    with _ctx(dev, w, h) as ctx:
+        ctx.upload(0, 0, left)
+        ctx.upload(0, 1, right)
+        ctx.build_pyramid([0, 0], [0, 1], 3, 21, with_gradients=False)
+        plain = dict(prev=(0, 0), next=(0, 1), prev_xy=pts, guess=guess)
+        stereo = dict(prev=(0, 0), next=(0, 1), prev_xy=pts, calib_prev=c0, calib_next=c1, stereo_Rt=Rt)
+        # flags without USE_INITIAL_FLOW for the stereo call: its guesses must be used all the same
+        g_plain, g_stereo = ctx.lk_track([plain, stereo], dev.LKParams(win=21, max_level=3, stereo_threshold=threshold))
+        only = ctx.lk_track([stereo], dev.LKParams(win=21, max_level=3, flags=0, stereo_threshold=threshold))[0]
+    assert np.array_equal(g_plain[0], r_xy) and np.array_equal(g_plain[1], r_st)      # the plain job of the batch is untouched
+    assert np.array_equal(g_stereo[0], r_xy) and np.array_equal(g_stereo[2], r_err)   # same seed -> same track
+    assert np.array_equal(g_stereo[1], want)
+    assert np.array_equal(only[0], r_xy) and np.array_equal(only[1], want)
+    if threshold >= 3.0 and not any(rot):
+        assert want.sum() >= 0.9 * r_st.sum()        # a row-wise displacement fits a sideways baseline
+    if threshold > 0:
+        assert want.sum() <= r_st.sum()
+
+
+def test_lk_stereo_job_with_outlier_rejection_and_missing_calibration(dev):
+    w, h = 640, 400
+    c0, c1, rot, t = STEREO_RIGS[1]
+    left, right = synth.shifted_pair(w, h, dx=-5, dy=0, seed=92)
+    pts = synth.random_points(w, h, 300, seed=93, border=4)
+    Rt = np.concatenate([synth.rotation_xyz(rot).reshape(9), np.asarray(t, dtype=np.float64)])
+    pl, pr = O.Pyramid(left, 15, 2), O.Pyramid(right, 15, 2)
+    r_xy, r_st, _ = O.lk_track(pl, pr, pts, guess=O.stereo_seed(pts, c0, c1, Rt), win=15, max_level=2)
+    want = O.reject_outliers(pts, r_xy, O.stereo_check(pts, r_xy, r_st, c0, c1, Rt, w, h, 3.0), c0, c1, hypotheses=64, seed=5)[0]
+    with _ctx(dev, w, h) as ctx:
+        ctx.upload(0, 0, left)
+        ctx.upload(0, 1, right)
+        ctx.build_pyramid([0, 0], [0, 1], 2, 15, with_gradients=False)
+        prm = dev.LKParams(win=15, max_level=2, flags=dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_REJECT_OUTLIERS, ransac_hypotheses=64, ransac_seed=5)
+        got = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts, calib_prev=c0, calib_next=c1, stereo_Rt=Rt)], prm)[0]
+        assert np.array_equal(got[0], r_xy) and np.array_equal(got[1], want)
+        with pytest.raises(dev.FtError):
+            ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts, stereo_Rt=Rt)], dev.LKParams(win=15, max_level=2))
+
+
 def test_error_codes(dev):
     with _ctx(dev, 128, 96, n_streams=1) as ctx:
         with pytest.raises(dev.FtError) as e:

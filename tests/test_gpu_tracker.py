@@ -61,14 +61,17 @@ def test_batch_tracker_with_outlier_rejection_matches_cpu_checker():
     assert gpu[1][1] == loose[1][1] and gpu[1][0] <= loose[1][0] - 20   # the patches' features went
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(reject_outliers=1)])
+@pytest.mark.parametrize("opts", [dict(), dict(reject_outliers=1), dict(stereo_extrinsic_seed=1),
+                                  dict(stereo_extrinsic_seed=1, stereo_threshold=0.4, reject_outliers=1)])
 def test_stereo_tracker_matches_cpu_checker(opts):
     O.lib()
     q = synth.Sequence(640, 400, 8, stream_id=7)
     runs = []
     for lib_path in (None, ORC):
         t = tracker.Tracker(640, 400, lib_path=lib_path, win_size=15, **opts)
-        t.set_calibration(np.stack([q.calib8, q.calib8]), np.stack([q.T_cam_imu, q.T_cam_imu]))
+        T_right = q.T_cam_imu.copy()
+        T_right[0, 3] += 0.11                     # sideways baseline, used by the extrinsic seed / known-E test
+        t.set_calibration(np.stack([q.calib8, q.calib8]), np.stack([q.T_cam_imu, T_right]))
         hist = []
         for i in range(8):
             t.feed_stereo(q.timestamps[i], q.frames[i], np.roll(q.frames[i], -5, axis=1))

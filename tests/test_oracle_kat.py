@@ -296,3 +296,52 @@ def test_reject_outliers_is_deterministic_and_keeps_lost_points_lost():
     assert few[1] == -1 and not few[0].any()                      # fewer than 8 pairs: nothing survives
     flat = O.reject_outliers(prev, prev * 0 + 5.0, np.ones(80, np.uint8), calib8)
     assert flat[1] == -1 and not flat[0].any()                    # degenerate data: no model
+
+
+# ---- stereo matching geometry (seed from the extrinsic rotation, known-E test) ----
+
+CAM0 = (458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+CAM1 = (457.587, 456.134, 379.999, 255.238, -0.28368365, 0.07451284, -0.00010473, -3.55590700e-05)
+
+
+def test_stereo_seed_is_the_projection_of_the_point_at_infinity():
+    import synth
+    # very distant points: the translation does not matter, the seed must land on the true cam1 pixel
+    a, b, Rt, _ = synth.stereo_views(200, CAM0, CAM1, seed=1, depth=(4000.0, 9000.0))
+    seed = O.stereo_seed(a, CAM0, CAM1, Rt)
+    assert np.abs(seed - b).max() < 0.05
+    # identity rotation, one undistorted camera: the seed is the point itself
+    pin = (460.0, 458.0, 376.0, 240.0, 0, 0, 0, 0)
+    eye = np.concatenate([np.eye(3).reshape(9), [-0.1, 0, 0]])
+    same = O.stereo_seed(a, pin, pin, eye)
+    assert np.abs(same - a).max() < 1e-3
+    # ... up to the float rounding of the normalized point between undistortPoints and projectPoints (cv::Point2f)
+    xn = ((a.astype(np.float64) - [376.0, 240.0]) * [1 / 460.0, 1 / 458.0]).astype(np.float32).astype(np.float64)
+    assert np.array_equal(same, (xn * [460.0, 458.0] + [376.0, 240.0]).astype(np.float32))
+    # a near point is displaced from its seed along the baseline by about fx * b / z
+    a, b, Rt, z = synth.stereo_views(200, pin, pin, rot=(0, 0, 0), t=(-0.11, 0, 0), seed=2)
+    seed = O.stereo_seed(a, pin, pin, Rt)
+    assert np.abs((b - seed)[:, 0] + 460.0 * 0.11 / z).max() < 0.01 and np.abs((b - seed)[:, 1]).max() < 0.01
+
+
+def test_stereo_check_keeps_true_matches_and_drops_off_line_and_outside_points():
+    import synth
+    a, b, Rt, _ = synth.stereo_views(300, CAM0, CAM1, seed=3)
+    inside = (b[:, 0] >= 0) & (b[:, 0] <= 751) & (b[:, 1] >= 0) & (b[:, 1] <= 479)
+    st = O.stereo_check(a, b, np.ones(300, np.uint8), CAM0, CAM1, Rt, 752, 480, 3.0)
+    assert np.array_equal(st == 1, inside)                         # exact geometry: only the frame test removes points
+    # 8 px off the (nearly horizontal) epipolar line: dropped; 1 px off: kept
+    off = b + np.array([0.0, 8.0], np.float32)
+    near = b + np.array([0.0, 1.0], np.float32)
+    ok = inside & (off[:, 1] <= 479) & (near[:, 1] <= 479)
+    assert not O.stereo_check(a, off, np.ones(300, np.uint8), CAM0, CAM1, Rt, 752, 480, 3.0)[ok].any()
+    assert O.stereo_check(a, near, np.ones(300, np.uint8), CAM0, CAM1, Rt, 752, 480, 3.0)[ok].all()
+    # sliding along the line never matters; lost points stay lost; threshold <= 0 leaves only the frame test
+    along = b + np.array([6.0, 0.0], np.float32)
+    ok2 = inside & (along[:, 0] <= 751)
+    assert O.stereo_check(a, along, np.ones(300, np.uint8), CAM0, CAM1, Rt, 752, 480, 3.0)[ok2].mean() > 0.97
+    lost = np.ones(300, np.uint8)
+    lost[::5] = 0
+    assert not O.stereo_check(a, b, lost, CAM0, CAM1, Rt, 752, 480, 3.0)[::5].any()
+    assert np.array_equal(O.stereo_check(a, off, np.ones(300, np.uint8), CAM0, CAM1, Rt, 752, 480, 0.0) == 1,
+                          (off[:, 0] >= 0) & (off[:, 0] <= 751) & (off[:, 1] >= 0) & (off[:, 1] <= 479))

@@ -158,6 +158,35 @@ def test_stereo_feed_tracks_both_cameras_and_fills_database(seq):
     assert np.allclose(uv[:, 2], (uv[:, 0] - seq.calib8[2]) / seq.calib8[0], atol=1e-5)
 
 
+def _stereo_run(seq, right_of, lib_path, n_frames=6, **opts):
+    t = tracker.Tracker(seq.w, seq.h, lib_path=lib_path, win_size=15, **opts)
+    T_right = seq.T_cam_imu.copy()
+    T_right[0, 3] += 0.11                         # sideways baseline: t_cam0_cam1 = (0.11, 0, 0)
+    t.set_calibration(np.stack([seq.calib8, seq.calib8]), np.stack([seq.T_cam_imu, T_right]))
+    hist = []
+    for i in range(n_frames):
+        t.feed_stereo(seq.timestamps[i], seq.frames[i], right_of(seq.frames[i]))
+        (xy_l, id_l), (xy_r, id_r) = t.points(0), t.points(1)
+        hist.append((xy_l, id_l, xy_r, id_r))
+    return hist
+
+
+def test_stereo_extrinsic_seed_accepts_row_disparity_and_rejects_column_disparity(seq):
+    """With the msckf_vio-style association (src/track/TrackMsckfVio.cpp:218-301) a right image displaced along the rows
+    fits the sideways baseline and gives stereo features; displaced along the columns it violates the known essential
+    matrix and gives none, whereas the plain same-pixel association accepts both."""
+    along = lambda f: np.roll(f, -5, axis=1)
+    across = lambda f: np.roll(f, -6, axis=0)
+
+    def common(h):
+        return len(np.intersect1d(h[-1][1], h[-1][3]))
+
+    assert common(_stereo_run(seq, along, ORC, stereo_extrinsic_seed=1)) > 60
+    assert common(_stereo_run(seq, across, ORC, stereo_extrinsic_seed=1)) <= 3          # (a track that slid along an edge may pass)
+    assert common(_stereo_run(seq, across, ORC)) > 60
+    assert common(_stereo_run(seq, across, ORC, stereo_extrinsic_seed=1, stereo_threshold=0.0)) > 60   # seed only, no test
+
+
 def test_mono_tracker_class_matches_batch_of_one(seq):
     t = tracker.Tracker(seq.w, seq.h, lib_path=ORC, win_size=21)
     t.set_calibration(np.stack([seq.calib8, seq.calib8]))
