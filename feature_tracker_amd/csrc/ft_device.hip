@@ -814,6 +814,9 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     G.size_x = w / grid_x; G.size_y = h / grid_y;                    // Grider_FAST.h:80-81
     if (G.size_x < 1 || G.size_y < 1 || G.size_x > 4096 || G.size_y > 4096) return FT_E_INVALID;
     G.ct_cols = w / G.size_x; G.ct_rows = h / G.size_y;              // Grider_FAST.h:91-92
+    G.inv_x = (uint32_t)(((1ull << 32) + (uint64_t)G.size_x - 1) / (uint64_t)G.size_x);   // unused for a size of 1
+    G.inv_y = (uint32_t)(((1ull << 32) + (uint64_t)G.size_y - 1) / (uint64_t)G.size_y);
+    if (w > 65535 || h > 65535) return FT_E_LIMIT;                   // range of the reciprocal division
     const int cells = G.ct_cols * G.ct_rows;
     if (cells > c->lim.max_grid_cells || per_cell > c->lim.max_per_cell) return FT_E_LIMIT;
     G.threshold = std::min(std::max(threshold, 0), 255);
@@ -838,7 +841,7 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     prof_begin(c, 2, ep);
     const int tiles = fast_tiles_x(w) * fast_tiles_y(h);
     hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(256), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
-    hipLaunchKernelGGL(fast_topk_kernel, dim3(n * cells), dim3(256), 0, c->q, G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, c->q, G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
     // cand is indexed [image*cells + cell][cand_cap], the keypoints [image*cells + cell][per_cell]

@@ -9,7 +9,7 @@
 //                        once, keeps pixels and scores in LDS, one global atomic per NMS survivor.  The kernel is
 //                        bound by vector-instruction issue, so the pre-test handles four pixels per lane from
 //                        dword LDS reads and the exact strength runs only on compacted candidates.
-//   fast_topk_kernel   : one workgroup per cell extracts the first `per_cell` candidates in the total order
+//   fast_topk_kernel   : one wavefront per cell extracts the first `per_cell` candidates in the total order
 //                        (score desc, y asc, x asc).
 #pragma once
 #include "ft_common.hpp"
@@ -23,7 +23,28 @@ struct FastGrid {
     int threshold;
     int per_cell;
     int cand_cap;           // candidate slots per cell
+    uint32_t inv_x, inv_y;  // ceil(2^32 / size): g / size == umulhi(g, inv) for g < 65536 and 2 <= size <= 4096
 };
+
+// coordinate / cell size without the integer-division sequence
+__device__ __forceinline__ int fast_cell_of(int g, int size, uint32_t inv) { return size == 1 ? g : (int)__umulhi((uint32_t)g, inv); }
+
+typedef unsigned short fd_v2u __attribute__((ext_vector_type(2)));
+
+// Compass pre-test for two pixels at once on packed 16-bit lanes: a 9-arc holds one pixel of every opposite pair, so a
+// corner needs (N or S) and (E or W) beyond the threshold on the same side.  Returns a non-zero half per passing pixel.
+__device__ __forceinline__ uint32_t fast_compass2(uint32_t c, uint32_t n, uint32_t s, uint32_t w, uint32_t e, uint32_t thr2) {
+    const fd_v2u C = __builtin_bit_cast(fd_v2u, c), N = __builtin_bit_cast(fd_v2u, n), S = __builtin_bit_cast(fd_v2u, s);
+    const fd_v2u W = __builtin_bit_cast(fd_v2u, w), E = __builtin_bit_cast(fd_v2u, e), T = __builtin_bit_cast(fd_v2u, thr2);
+    const fd_v2u lo = __builtin_elementwise_sub_sat(C, T), hi = C + T;
+    const fd_v2u dark = __builtin_elementwise_min(
+        __builtin_elementwise_max(__builtin_elementwise_sub_sat(lo, N), __builtin_elementwise_sub_sat(lo, S)),
+        __builtin_elementwise_max(__builtin_elementwise_sub_sat(lo, E), __builtin_elementwise_sub_sat(lo, W)));
+    const fd_v2u bright = __builtin_elementwise_min(
+        __builtin_elementwise_max(__builtin_elementwise_sub_sat(N, hi), __builtin_elementwise_sub_sat(S, hi)),
+        __builtin_elementwise_max(__builtin_elementwise_sub_sat(E, hi), __builtin_elementwise_sub_sat(W, hi)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright));
+}
 
 // strength = max over the 16 arcs of 9 contiguous circle pixels of min(d) (darker arc) or min(-d) (brighter arc),
 // d[k] = v - p[k].  The pixel is a corner iff strength > threshold; its OpenCV score is strength - 1.
@@ -116,45 +137,56 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     // cell membership is separable: one division per column and per row of the container instead of two per pixel
     if (t < FD_CW) {
         const int gx = CX0 + t;
-        const int cxi = gx / G.size_x, lx = gx - cxi * G.size_x;
+        const int cxi = fast_cell_of(gx, G.size_x, G.inv_x), lx = gx - cxi * G.size_x;
         col_ok[t] = (gx < G.w && cxi < G.ct_cols && lx >= 3 && lx < G.size_x - 3) ? 1 : 0;
     } else if (t >= 128 && t < 128 + FD_CH) {
         const int gy = OY - 1 + (t - 128);
-        const int cyi = gy >= 0 ? gy / G.size_y : 0, ly = gy - cyi * G.size_y;
+        const int cyi = gy >= 0 ? fast_cell_of(gy, G.size_y, G.inv_y) : 0, ly = gy - cyi * G.size_y;
         row_ok[t - 128] = (gy >= 0 && gy < G.h && cyi < G.ct_rows && ly >= 3 && ly < G.size_y - 3) ? 1 : 0;
     }
     __syncthreads();
 
-    // ---- compass test, four pixels per task: a 9-arc holds one pixel of every opposite pair ----
+    // ---- compass test, four pixels per task as two packed pairs ----
     const int thr = G.threshold;
+    const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
     const int d = t & 15;                                                    // container dword column of this thread
-    const uint32_t colmask = *reinterpret_cast<const uint32_t*>(&col_ok[4 * d]);   // one byte per column
+    const uint32_t colbytes = *reinterpret_cast<const uint32_t*>(&col_ok[4 * d]);   // one byte per column
+    const uint32_t colbits = (colbytes & 1u) | ((colbytes >> 7) & 2u) | ((colbytes >> 14) & 4u) | ((colbytes >> 21) & 8u);
 #pragma unroll
     for (int round = 0; round < 2; round++) {
         const int r = (t >> 4) + 16 * round;                                 // container row
         uint32_t hits = 0;
-        if (colmask != 0 && row_ok[r]) {
+        if (colbits != 0 && row_ok[r]) {
             const uint8_t* p = &pix[(r + 3) * FD_PPITCH + 8 + 4 * d];
             const uint32_t C = *reinterpret_cast<const uint32_t*>(p);
             const uint32_t Wd = *reinterpret_cast<const uint32_t*>(p - 4), Ed = *reinterpret_cast<const uint32_t*>(p + 4);
             const uint32_t N = *reinterpret_cast<const uint32_t*>(p - 3 * FD_PPITCH), S = *reinterpret_cast<const uint32_t*>(p + 3 * FD_PPITCH);
-            const uint64_t we = ((uint64_t)C << 32) | Wd, ce = ((uint64_t)Ed << 32) | C;   // bytes x-4..x+3 and x..x+7
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = (C >> (8 * j)) & 0xff, lo = v - thr, hi = v + thr;
-                const int n = (N >> (8 * j)) & 0xff, s = (S >> (8 * j)) & 0xff;
-                const int w3 = (int)((we >> (8 * (j + 1))) & 0xff);          // pixel x+j-3
-                const int e3 = (int)((ce >> (8 * (j + 3))) & 0xff);          // pixel x+j+3
-                const bool dark = (n < lo || s < lo) && (e3 < lo || w3 < lo);
-                const bool bright = (n > hi || s > hi) && (e3 > hi || w3 > hi);
-                if ((dark || bright) && ((colmask >> (8 * j)) & 1)) hits |= 1u << j;
-            }
+            // bytes -> 16-bit lanes (v_perm_b32: selector bytes 0-3 take from the second operand, 4-7 from the first, 0x0c = 0)
+            const uint32_t m01 = fast_compass2(__builtin_amdgcn_perm(0u, C, 0x0c010c00u), __builtin_amdgcn_perm(0u, N, 0x0c010c00u),
+                                               __builtin_amdgcn_perm(0u, S, 0x0c010c00u), __builtin_amdgcn_perm(C, Wd, 0x0c020c01u),
+                                               __builtin_amdgcn_perm(Ed, C, 0x0c040c03u), thr2);      // pixels x, x+1: W = x-3, x-2; E = x+3, x+4
+            const uint32_t m23 = fast_compass2(__builtin_amdgcn_perm(0u, C, 0x0c030c02u), __builtin_amdgcn_perm(0u, N, 0x0c030c02u),
+                                               __builtin_amdgcn_perm(0u, S, 0x0c030c02u), __builtin_amdgcn_perm(C, Wd, 0x0c040c03u),
+                                               __builtin_amdgcn_perm(Ed, C, 0x0c060c05u), thr2);      // pixels x+2, x+3: W = x-1, x; E = x+5, x+6
+            hits = ((m01 & 0xffffu) ? 1u : 0u) | ((m01 >> 16) ? 2u : 0u) | ((m23 & 0xffffu) ? 4u : 0u) | ((m23 >> 16) ? 8u : 0u);
+            hits &= colbits;
         }
-        if (hits) {
-            int at = atomicAdd(&list_n, __builtin_popcount(hits));
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (hits & (1u << j)) list[at++] = (uint16_t)((r << 6) | (4 * d + j));
+        // Compaction, one LDS atomic per wavefront: the wave's entries are laid out by pixel position within the task
+        // (all first pixels, then all second pixels, ...), each group ranked with a ballot.  The list is unordered anyway.
+        {
+            const uint64_t b0 = __ballot(hits & 1u), b1 = __ballot(hits & 2u), b2 = __ballot(hits & 4u), b3 = __ballot(hits & 8u);
+            const int n0 = __builtin_popcountll(b0), n1 = __builtin_popcountll(b1), n2 = __builtin_popcountll(b2), n3 = __builtin_popcountll(b3);
+            const int total = n0 + n1 + n2 + n3;
+            if (total) {   // uniform for the wave
+                int base = 0;
+                if ((t & 63) == 0) base = atomicAdd(&list_n, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint16_t key = (uint16_t)((r << 6) | (4 * d));
+                if (hits & 1u) list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))] = key;
+                if (hits & 2u) list[base + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))] = key | 1;
+                if (hits & 4u) list[base + n0 + n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u))] = key | 2;
+                if (hits & 8u) list[base + n0 + n1 + n2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, 0u))] = key | 3;
+            }
         }
     }
     __syncthreads();
@@ -191,7 +223,7 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
             if (s > q[-1] && s > q[1] && s > q[-FD_CW - 1] && s > q[-FD_CW] && s > q[-FD_CW + 1] &&
                 s > q[FD_CW - 1] && s > q[FD_CW] && s > q[FD_CW + 1]) {
                 const int gx = CX0 + col, gy = OY - 1 + r;
-                const int cxi = gx / G.size_x, cyi = gy / G.size_y;
+                const int cxi = fast_cell_of(gx, G.size_x, G.inv_x), cyi = fast_cell_of(gy, G.size_y, G.inv_y);
                 const int gcell = img_i * cells + cyi * G.ct_cols + cxi;
                 const int at = atomicAdd(&cand_count[gcell], 1);
                 if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
@@ -200,32 +232,47 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     }
 }
 
-// one workgroup per (image, cell): repeated "largest key below the previous one".  Also reports the number of NMS
-// survivors of the cell and leaves the cell's candidate counter at zero for the next detector pass.
+// wave-wide maximum (result uniform in all lanes): four DPP stages inside the rows of 16 lanes, two across rows
+__device__ __forceinline__ uint32_t fast_wave_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast15 into rows 1,3
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast31 into rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// One wavefront per (image, cell), four cells per workgroup: repeated "largest key below the previous one" with the
+// first 256 candidates of the cell in registers (a cell rarely has more than a few dozen NMS survivors).  Also
+// reports the number of NMS survivors of the cell and leaves its candidate counter at zero for the next detector pass.
+constexpr int FT_TOPK_REGS = 4;
 __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32_t* __restrict__ cand, int* __restrict__ cand_count,
-                                                       ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count) {
-    __shared__ uint32_t red[4];
-    const int gcell = blockIdx.x;
+                                                       ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count,
+                                                       int total_cells) {
+    const int lane = threadIdx.x & 63;
+    const int gcell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gcell >= total_cells) return;          // uniform for the wave
     const int cell = gcell % (G.ct_cols * G.ct_rows);
     const int survivors = cand_count[gcell];
     const int n = min(survivors, G.cand_cap);
     const uint32_t* c = cand + (uint64_t)gcell * G.cand_cap;
     const int keep = min(n, G.per_cell);
     const int cell_x = (cell % G.ct_cols) * G.size_x, cell_y = (cell / G.ct_cols) * G.size_y;
+    uint32_t key[FT_TOPK_REGS];
+#pragma unroll
+    for (int k = 0; k < FT_TOPK_REGS; k++) key[k] = (lane + 64 * k < n) ? c[lane + 64 * k] : 0u;
     uint32_t bound = 0xffffffffu;
     for (int r = 0; r < keep; r++) {
         uint32_t best = 0;
-        for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+        for (int k = 0; k < FT_TOPK_REGS; k++) best = max(best, key[k] < bound ? key[k] : 0u);
+        for (int i = lane + 64 * FT_TOPK_REGS; i < n; i += 64) {
             const uint32_t k = c[i];
             if (k < bound && k > best) best = k;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
-        __syncthreads();
-        best = max(max(red[0], red[1]), max(red[2], red[3]));
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        best = fast_wave_max(best);
+        if (lane == 0) {
             ft_keypoint kp;
             kp.x = (float)(cell_x + 4095 - (int)(best & 0xfff));
             kp.y = (float)(cell_y + 4095 - (int)((best >> 12) & 0xfff));
@@ -234,8 +281,7 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32
         }
         bound = best;
     }
-    __syncthreads();   // every thread has read the counter
-    if (threadIdx.x == 0) {
+    if (lane == 0) {   // after the wave's read of the counter above (program order within the wave)
         out_count[gcell] = keep;
         surv_count[gcell] = survivors;
         cand_count[gcell] = 0;

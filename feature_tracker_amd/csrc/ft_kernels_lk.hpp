@@ -96,6 +96,25 @@ __device__ __forceinline__ void wave_sum3_i32(int& a, int& b, int& c) {
     c = __builtin_amdgcn_readlane(c, 63);
 }
 
+// the same for two chains
+__device__ __forceinline__ void wave_sum2_i32(int& a, int& b) {
+#define LK_DPP_STAGE2(ctrl, rmask)                                                    \
+    {                                                                                  \
+        const int ta = __builtin_amdgcn_update_dpp(0, a, ctrl, rmask, 0xF, false);     \
+        const int tb = __builtin_amdgcn_update_dpp(0, b, ctrl, rmask, 0xF, false);     \
+        a += ta; b += tb;                                                              \
+    }
+    LK_DPP_STAGE2(0xB1, 0xF)
+    LK_DPP_STAGE2(0x4E, 0xF)
+    LK_DPP_STAGE2(0x141, 0xF)
+    LK_DPP_STAGE2(0x140, 0xF)
+    LK_DPP_STAGE2(0x142, 0xA)
+    LK_DPP_STAGE2(0x143, 0xC)
+#undef LK_DPP_STAGE2
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+}
+
 // sums over the wave of two int32 values per lane with |v| < 2^30, exactly, as floats rounded once.  The low 10
 // bits of both travel in one register (two 16-bit fields: 64 * 1023 < 2^16), the high parts in one register each.
 __device__ __forceinline__ void wave_sum_exact2(int v1, int v2, float& s1, float& s2) {
@@ -107,9 +126,9 @@ __device__ __forceinline__ void wave_sum_exact2(int v1, int v2, float& s1, float
 // the same for three values: two registers of low parts, three of high parts
 __device__ __forceinline__ void wave_sum_exact3(int v1, int v2, int v3, float& s1, float& s2, float& s3) {
     int slo = (v1 & 1023) | ((v2 & 1023) << 16), sh1 = v1 >> 10, sh2 = v2 >> 10;
-    int slo3 = v3 & 1023, sh3 = v3 >> 10, zero = 0;
+    int slo3 = v3 & 1023, sh3 = v3 >> 10;
     wave_sum3_i32(slo, sh1, sh2);
-    wave_sum3_i32(slo3, sh3, zero);
+    wave_sum2_i32(slo3, sh3);
     s1 = (float)((double)sh1 * 1024.0 + (double)(slo & 0xffff));
     s2 = (float)((double)sh2 * 1024.0 + (double)((uint32_t)slo >> 16));
     s3 = (float)((double)sh3 * 1024.0 + (double)slo3);
