@@ -236,11 +236,11 @@ def test_fast_grid_batched_and_plateaus(dev):
 CALIBS = [np.array([458.7, 457.3, 367.2, 248.4, -0.28, 0.074, 2e-4, 2e-5]), np.array([600., 600., 376., 240., 0, 0, 0, 0])]
 
 
-@pytest.mark.parametrize("n,n_out,seed", [(150, 30, 1), (8, 0, 2), (400, 200, 3), (64, 50, 4)])
+@pytest.mark.parametrize("n,n_out,seed", [(150, 30, 1), (8, 0, 2), (400, 200, 3), (64, 50, 4), (3000, 900, 5)])   # last: beyond the LDS-resident part
 def test_reject_outliers_equals_oracle(dev, n, n_out, seed):
     """Standalone rejection on synthetic two-view matches: the status bytes equal the CPU checker's bit for bit
     (same hash-drawn samples, same double-precision elimination, same float error measure)."""
-    ctx = _ctx(dev, 64, 64, max_points=1200)
+    ctx = _ctx(dev, 64, 64, max_points=2 * n + 400)
     sets, want = [], []
     rng = np.random.default_rng(seed)
     for k, calib in enumerate(CALIBS):
