@@ -17,6 +17,7 @@
 #include "ft_common.hpp"
 #include "ft_kernels_fast.hpp"
 #include "ft_kernels_lk.hpp"
+#include "ft_kernels_match.hpp"
 #include "ft_kernels_outlier.hpp"
 #include "ft_kernels_pyramid.hpp"
 #include "ft_kernels_stereo.hpp"
@@ -83,6 +84,8 @@ struct ft_ctx {
     uint8_t* lk_out_host_dev = nullptr;   // device-side address of lk_out_host
     float4* lk_norm_dev = nullptr;        // outlier rejection: normalized point pairs
     RansacPartial* ransac_part_dev = nullptr;   // outlier rejection: best model of every workgroup
+    // descriptor matching, allocated on first use: both descriptor sets and both neighbour tables, device + pinned host
+    uint8_t* match_dev = nullptr;  uint8_t* match_host = nullptr;  size_t match_cap = 0;   // descriptors per set
     PendingLK lk_pending;
 
     // FAST scratch
@@ -430,6 +433,8 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
     if (c->ransac_part_dev) (void)hipFree(c->ransac_part_dev);
+    if (c->match_dev) (void)hipFree(c->match_dev);
+    if (c->match_host) (void)hipHostFree(c->match_host);
     if (c->cand) (void)hipFree(c->cand);
     if (c->cand_count) (void)hipFree(c->cand_count);
     for (auto& h : c->fast_out_host) if (h) (void)hipHostFree(h);
@@ -873,6 +878,61 @@ void ft_homography(const float* K4, const float* R, float* H) {
         H[3 + col] = fy * M[3 + col] + cy * M[6 + col];
         H[6 + col] = M[6 + col];
     }
+}
+
+int ft_match_descriptors(ft_ctx* c, const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, ft_match* out, int cap, int* n_out) {
+    if (!c || !n_out || n0 < 0 || n1 < 0 || cap < 0 || (cap > 0 && !out) || (n0 > 0 && !desc0) || (n1 > 0 && !desc1)) return FT_E_INVALID;
+    if (n0 > 65536 || n1 > 65536) return FT_E_LIMIT;
+    *n_out = 0;
+    if (n0 == 0 || n1 == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    const size_t need = (size_t)std::max(n0, n1);
+    if (need > c->match_cap) {
+        FT_HIP(c, hipStreamSynchronize(c->q));
+        if (c->match_dev) (void)hipFree(c->match_dev);
+        if (c->match_host) (void)hipHostFree(c->match_host);
+        c->match_dev = nullptr; c->match_host = nullptr; c->match_cap = 0;
+        const size_t cap_n = align_up(need, 1024);
+        void* p = nullptr;
+        FT_HIP(c, hipMalloc(&p, cap_n * (32 + 8) * 2));
+        c->match_dev = (uint8_t*)p;
+        FT_HIP(c, hipHostMalloc(&p, cap_n * (32 + 8) * 2, hipHostMallocDefault));
+        c->match_host = (uint8_t*)p;
+        c->match_cap = cap_n;
+    }
+    // layout of both blocks: descriptors of set 0, of set 1, neighbour table of set 0, of set 1
+    const size_t M = c->match_cap;
+    const size_t off_d1 = 32 * M, off_b0 = 64 * M, off_b1 = 72 * M;
+    memcpy(c->match_host, desc0, 32 * (size_t)n0);
+    memcpy(c->match_host + off_d1, desc1, 32 * (size_t)n1);
+    FT_HIP(c, hipMemcpyAsync(c->match_dev, c->match_host, 32 * (size_t)n0, hipMemcpyHostToDevice, c->q));
+    FT_HIP(c, hipMemcpyAsync(c->match_dev + off_d1, c->match_host + off_d1, 32 * (size_t)n1, hipMemcpyHostToDevice, c->q));
+    const uint4* d0 = reinterpret_cast<const uint4*>(c->match_dev);
+    const uint4* d1 = reinterpret_cast<const uint4*>(c->match_dev + off_d1);
+    hipLaunchKernelGGL(hamming_knn2_kernel, dim3((n0 + 3) / 4), dim3(256), 0, c->q, d0, n0, d1, n1, reinterpret_cast<uint2*>(c->match_dev + off_b0));
+    hipLaunchKernelGGL(hamming_knn2_kernel, dim3((n1 + 3) / 4), dim3(256), 0, c->q, d1, n1, d0, n0, reinterpret_cast<uint2*>(c->match_dev + off_b1));
+    FT_HIP(c, hipGetLastError());
+    FT_HIP(c, hipMemcpyAsync(c->match_host + off_b0, c->match_dev + off_b0, 8 * (size_t)n0, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipMemcpyAsync(c->match_host + off_b1, c->match_dev + off_b1, 8 * (size_t)n1, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    // ratio and symmetry tests: O(n) on the host (TrackDescriptor.cpp:309-354)
+    const uint2* b0 = reinterpret_cast<const uint2*>(c->match_host + off_b0);
+    const uint2* b1 = reinterpret_cast<const uint2*>(c->match_host + off_b1);
+    auto surviving = [knn_ratio](const uint2& b) -> int {
+        if (b.y == MATCH_NONE) return -1;                                    // fewer than two neighbours
+        const float first = (float)(b.x >> MATCH_IDX_BITS), second = (float)(b.y >> MATCH_IDX_BITS);
+        if (first / second > knn_ratio) return -1;
+        return (int)(b.x & ((1u << MATCH_IDX_BITS) - 1));
+    };
+    int n = 0;
+    for (int i = 0; i < n0; i++) {
+        const int j = surviving(b0[i]);
+        if (j < 0 || surviving(b1[j]) != i) continue;
+        if (n < cap) { out[n].query = i; out[n].train = j; out[n].distance = (float)(b0[i].x >> MATCH_IDX_BITS); }
+        n++;
+    }
+    *n_out = n;
+    return FT_OK;
 }
 
 int ft_predict_flow(ft_ctx* c, const float* H, const float* xy, float* xy_out, int n) {

@@ -49,6 +49,10 @@ class ft_match_set(C.Structure):
                 ("calib_prev", C.c_void_p), ("calib_next", C.c_void_p)]
 
 
+class ft_match(C.Structure):
+    _fields_ = [("query", C.c_int), ("train", C.c_int), ("distance", C.c_float)]
+
+
 class ft_keypoint(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("response", C.c_float)]
 
@@ -62,7 +66,7 @@ class ft_kernel_time(C.Structure):
 # every symbol include/ft_device.h declares
 SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device",
            "ft_set_frames_device_pyramid", "ft_build_pyramid",
-           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_fast_grid", "ft_fast_grid_async",
+           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_match_descriptors", "ft_fast_grid", "ft_fast_grid_async",
            "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
            "ft_last_hip_error", "ft_device_count"]
@@ -108,6 +112,7 @@ def load_library():
     lib.ft_build_gradients.argtypes = [vp, C.c_int, ip, ip]
     lib.ft_lk_track.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
     lib.ft_lk_track_async.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
+    lib.ft_match_descriptors.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.POINTER(ft_match), C.c_int, ip]
     lib.ft_reject_outliers.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
     lib.ft_reject_outliers_async.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
     fg = [vp, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ft_keypoint), C.c_int, ip, ip]
@@ -310,6 +315,17 @@ class DeviceContext:
             outs.append(st)
         self._check(self.lib.ft_reject_outliers(self._ctx, len(sets), cs, hypotheses, seed), "ft_reject_outliers")
         return outs
+
+    def match_descriptors(self, desc0, desc1, knn_ratio=0.7):
+        """desc0 (n0, 32), desc1 (n1, 32) uint8.  Returns (m, 3) int32 rows (query, train, distance) in query order."""
+        a = np.ascontiguousarray(desc0, dtype=np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+        cap = max(1, a.shape[0])
+        out = (ft_match * cap)()
+        n = C.c_int(0)
+        self._check(self.lib.ft_match_descriptors(self._ctx, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], knn_ratio, out, cap,
+                                                  C.byref(n)), "ft_match_descriptors")
+        return np.array([(out[i].query, out[i].train, int(out[i].distance)) for i in range(n.value)], dtype=np.int32).reshape(-1, 3)
 
     # -- FAST --
     def fast_grid(self, streams, slots, threshold=20, grid_x=5, grid_y=5, per_cell=7, cap=None, sync=True):

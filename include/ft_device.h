@@ -109,6 +109,12 @@ typedef struct ft_match_set {
     const double* calib_next;     /* ... of the second image's camera */
 } ft_match_set;
 
+/* One accepted descriptor match (cv::DMatch: queryIdx, trainIdx, distance). */
+typedef struct ft_match {
+    int query, train;
+    float distance;      /* Hamming distance, 0..256 */
+} ft_match;
+
 typedef struct ft_keypoint {
     float x, y;          /* full-image pixel position */
     float response;      /* FAST score */
@@ -173,6 +179,17 @@ int ft_fast_grid_async(ft_ctx* ctx, int n, const int* streams, const int* slots,
                        int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts);
 
 /* H = K*R*K^-1 (host, float32; K4 = fx,fy,cx,cy) and the device point warp p' = pi(H*[p;1]). */
+/* Matching of two sets of 256-bit binary descriptors (ORB rows, 32 bytes each) as TrackDescriptor::robust_match does
+ * it before its RANSAC (src/track/TrackDescriptor.cpp:249-265, :309-354): the two nearest neighbours of every
+ * descriptor in the other set, both ways (cv::BFMatcher(NORM_HAMMING).knnMatch(…, 2); equal distances: the lower
+ * index first), the ratio test distance[0] / distance[1] > knn_ratio -> dropped (also dropped: fewer than two
+ * neighbours), and the symmetry test (query -> train kept only if train's own surviving match is query).  Accepted
+ * matches are written in query order; *n_out is their number (at most cap are written).  The reference's RANSAC tail
+ * (:267-304) is ft_reject_outliers on the matched points.  Descriptor extraction (cv::ORB::compute, :218-219) is not
+ * part of this library.  Synchronous; n0, n1 <= 65536. */
+int ft_match_descriptors(ft_ctx* ctx, const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio,
+                         ft_match* out, int cap, int* n_out);
+
 void ft_homography(const float* K4, const float* R_p_c, float* H);
 int ft_predict_flow(ft_ctx* ctx, const float* H, const float* xy, float* xy_out, int n);
 

@@ -821,4 +821,32 @@ void fto_stereo_check(const float* cam0_xy, const float* cam1_xy, uint8_t* statu
     }
 }
 
+int fto_match_descriptors(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, int* out_qtd, int cap) {
+    struct Two { int i1 = -1, d1 = 0, i2 = -1, d2 = 0; };
+    auto knn2 = [](const uint8_t* q, int nq, const uint8_t* t, int nt) {
+        std::vector<Two> r((size_t)nq);
+        for (int i = 0; i < nq; i++) {
+            Two b;
+            for (int j = 0; j < nt; j++) {
+                int d = 0;
+                for (int k = 0; k < 32; k++) d += __builtin_popcount((unsigned)(q[32 * i + k] ^ t[32 * j + k]));
+                if (b.i1 < 0 || d < b.d1) { b.i2 = b.i1; b.d2 = b.d1; b.i1 = j; b.d1 = d; }   // strict: the earlier index keeps its place
+                else if (b.i2 < 0 || d < b.d2) { b.i2 = j; b.d2 = d; }
+            }
+            r[(size_t)i] = b;
+        }
+        return r;
+    };
+    const std::vector<Two> a = knn2(desc0, n0, desc1, n1), b = knn2(desc1, n1, desc0, n0);
+    auto surviving = [knn_ratio](const Two& m) { return (m.i2 < 0 || (float)m.d1 / (float)m.d2 > knn_ratio) ? -1 : m.i1; };
+    int n = 0;
+    for (int i = 0; i < n0; i++) {
+        const int j = surviving(a[(size_t)i]);
+        if (j < 0 || surviving(b[(size_t)j]) != i) continue;
+        if (n < cap) { out_qtd[3 * n] = i; out_qtd[3 * n + 1] = j; out_qtd[3 * n + 2] = a[(size_t)i].d1; }
+        n++;
+    }
+    return n;
+}
+
 }  // extern "C"

@@ -128,6 +128,12 @@ void fto_stereo_seed(const float* cam0_xy, int n, const double* calib8_cam0, con
 void fto_stereo_check(const float* cam0_xy, const float* cam1_xy, uint8_t* status, int n, const double* calib8_cam0,
                       const double* calib8_cam1, const double* Rt12, int w, int h, double threshold);
 
+/* Descriptor matching of TrackDescriptor::robust_match before its RANSAC (src/track/TrackDescriptor.cpp:249-265,
+ * :309-354) on 32-byte binary descriptors: 2 nearest neighbours by Hamming distance both ways (equal distances: the
+ * lower index first), ratio test first / second > knn_ratio -> dropped, symmetry test.  out_qtd receives
+ * (query, train, distance) int triples in query order; returns the number of matches (all counted, at most cap written). */
+int fto_match_descriptors(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, int* out_qtd, int cap);
+
 #ifdef __cplusplus
 }
 #endif

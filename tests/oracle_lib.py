@@ -218,3 +218,14 @@ def stereo_check(cam0_xy, cam1_xy, status, calib8_cam0, calib8_cam1, Rt12, w, h,
     L.fto_stereo_check.restype = None
     L.fto_stereo_check(a.ctypes.data, b.ctypes.data, st.ctypes.data, a.shape[0], c0.ctypes.data, c1.ctypes.data, rt.ctypes.data, w, h, threshold)
     return st
+
+
+def match_descriptors(desc0, desc1, knn_ratio=0.7):
+    """(m, 3) int32 rows (query, train, distance): 2-NN Hamming both ways + ratio test + symmetry test."""
+    a = np.ascontiguousarray(desc0, dtype=np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros((max(1, a.shape[0]), 3), dtype=np.int32)
+    L = lib()
+    L.fto_match_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
+    n = L.fto_match_descriptors(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], knn_ratio, out.ctypes.data, out.shape[0])
+    return out[:n].copy()

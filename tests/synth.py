@@ -138,3 +138,20 @@ def stereo_views(n, calib8_cam0, calib8_cam1, rot=(0.004, -0.01, 0.006), t=(-0.1
     a = project_brown(X, calib8_cam0)
     b = project_brown(X @ R.T + np.asarray(t), calib8_cam1)
     return a.astype(np.float32), b.astype(np.float32), np.concatenate([R.reshape(9), np.asarray(t, dtype=np.float64)]), z
+
+
+def descriptor_sets(n_common, n_only0, n_only1, flip_bits=12, seed=0):
+    """Two shuffled sets of random 256-bit descriptors sharing n_common items, the shared ones in set 1 with up to
+    flip_bits random bits flipped.  Returns (desc0, desc1, pairs) with pairs = (index in set 0, index in set 1)."""
+    rng = np.random.default_rng(seed)
+    common = rng.integers(0, 256, (n_common, 32), dtype=np.uint8)
+    noisy = common.copy()
+    for i in range(n_common):
+        for b in rng.integers(0, 256, rng.integers(0, flip_bits + 1)):
+            noisy[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    d0 = np.concatenate([common, rng.integers(0, 256, (n_only0, 32), dtype=np.uint8)])
+    d1 = np.concatenate([noisy, rng.integers(0, 256, (n_only1, 32), dtype=np.uint8)])
+    p0, p1 = rng.permutation(len(d0)), rng.permutation(len(d1))
+    inv0, inv1 = np.argsort(p0), np.argsort(p1)
+    pairs = np.stack([inv0[:n_common], inv1[:n_common]], axis=1)
+    return d0[p0], d1[p1], pairs[np.argsort(pairs[:, 0])]

@@ -353,6 +353,24 @@ def test_lk_stereo_job_with_outlier_rejection_and_missing_calibration(dev):
             ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts, stereo_Rt=Rt)], dev.LKParams(win=15, max_level=2))
 
 
+@pytest.mark.parametrize("n_common,n0,n1,flips,ratio,seed", [(120, 40, 60, 12, 0.7, 1), (700, 300, 500, 40, 0.85, 2), (5, 0, 0, 3, 0.75, 3),
+                                                             (300, 0, 0, 90, 0.95, 4)])
+def test_match_descriptors_equals_oracle(dev, n_common, n0, n1, flips, ratio, seed):
+    """Hamming 2-NN on the device + ratio/symmetry tests = the CPU checker, match for match (integers: exact)."""
+    d0, d1, pairs = synth.descriptor_sets(n_common, n0, n1, flip_bits=flips, seed=seed)
+    # duplicates make equal distances, where the lower index must win on both sides
+    d1[len(d1) // 2] = d1[0]
+    want = O.match_descriptors(d0, d1, knn_ratio=ratio)
+    with _ctx(dev, 64, 64) as ctx:
+        got = ctx.match_descriptors(d0, d1, knn_ratio=ratio)
+        assert np.array_equal(got, want)
+        assert len(ctx.match_descriptors(d0[:0], d1)) == 0 and len(ctx.match_descriptors(d0, d1[:1])) == 0
+        again = ctx.match_descriptors(d1, d0, knn_ratio=ratio)          # a second call reuses the buffers
+        assert np.array_equal(again, O.match_descriptors(d1, d0, knn_ratio=ratio))
+    if flips <= 12:
+        assert len(want) >= n_common - 2
+
+
 def test_error_codes(dev):
     with _ctx(dev, 128, 96, n_streams=1) as ctx:
         with pytest.raises(dev.FtError) as e:

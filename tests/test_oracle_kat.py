@@ -345,3 +345,37 @@ def test_stereo_check_keeps_true_matches_and_drops_off_line_and_outside_points()
     assert not O.stereo_check(a, b, lost, CAM0, CAM1, Rt, 752, 480, 3.0)[::5].any()
     assert np.array_equal(O.stereo_check(a, off, np.ones(300, np.uint8), CAM0, CAM1, Rt, 752, 480, 0.0) == 1,
                           (off[:, 0] >= 0) & (off[:, 0] <= 751) & (off[:, 1] >= 0) & (off[:, 1] <= 479))
+
+
+# ---- descriptor matching (Hamming 2-NN both ways, ratio test, symmetry test) ----
+
+def test_match_descriptors_finds_planted_pairs_and_nothing_else():
+    import synth
+    d0, d1, pairs = synth.descriptor_sets(120, 40, 60, flip_bits=12, seed=1)
+    m = O.match_descriptors(d0, d1, knn_ratio=0.7)
+    assert np.array_equal(m[:, :2], pairs)                       # every planted pair, in query order, and no random pair
+    want = np.array([np.unpackbits(d0[i] ^ d1[j]).sum() for i, j in pairs])
+    assert np.array_equal(m[:, 2], want) and want.max() <= 12
+
+
+def test_match_descriptors_ratio_symmetry_and_degenerate_sets():
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    # query 0 has two equally good candidates (its copy twice): ratio 0/0 is not "> ratio", the lower index wins,
+    # and the symmetry test keeps it only if that candidate points back
+    d1 = np.concatenate([base[:1], base[:1], base[1:]])
+    m = O.match_descriptors(base, d1, knn_ratio=0.7)
+    assert [tuple(r) for r in m[:, :2]] == [(0, 0), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6)]
+    # an ambiguous query (two train descriptors at almost the same distance) fails the ratio test
+    amb = base[2].copy(); amb[0] ^= 1
+    amb2 = base[2].copy(); amb2[1] ^= 1
+    q = base[2].copy(); q[2] ^= 1
+    assert len(O.match_descriptors(np.stack([q, base[5]]), np.stack([amb, amb2]), knn_ratio=0.7)) == 0
+    assert [tuple(r) for r in O.match_descriptors(np.stack([q, base[5]]), np.stack([amb, base[4]]), knn_ratio=0.7)] == [(0, 0, 2)]
+    # a train set with fewer than two descriptors has no second neighbour: nothing survives; empty sets
+    assert len(O.match_descriptors(base, base[:1], knn_ratio=0.7)) == 0
+    assert len(O.match_descriptors(base[:0], base, knn_ratio=0.7)) == 0 and len(O.match_descriptors(base, base[:0], knn_ratio=0.7)) == 0
+    # symmetry: two queries competing for one train descriptor, only its own nearest is accepted
+    near = base[3].copy(); near[5] ^= 0x0f
+    m = O.match_descriptors(np.stack([near, base[3]]), np.stack([base[3], base[0]]), knn_ratio=0.7)
+    assert [tuple(r) for r in m] == [(1, 0, 0)]
