@@ -115,9 +115,19 @@ __device__ __forceinline__ void wave_sum2_i32(int& a, int& b) {
     b = __builtin_amdgcn_readlane(b, 63);
 }
 
-// sums over the wave of two int32 values per lane with |v| < 2^30, exactly, as floats rounded once.  The low 10
-// bits of both travel in one register (two 16-bit fields: 64 * 1023 < 2^16), the high parts in one register each.
+// sums over the wave of two int32 values per lane with |v| < 2^30, exactly, as floats rounded once.
+// Usual case, decided for the whole wave: every |v| < 2^25, so the 64-lane sums fit an int32 and two plain chains
+// do, with one int -> float conversion each.  Otherwise the low 10 bits of both travel in one register (two 16-bit
+// fields: 64 * 1023 < 2^16) and the high parts in one register each.
+__device__ __forceinline__ bool lk_any_lane_big(uint32_t biased_or) {   // biased_or: OR of (v + 2^25) over the lane's values
+    return __builtin_amdgcn_ballot_w64((biased_or >> 26) != 0u) != 0ull;
+}
 __device__ __forceinline__ void wave_sum_exact2(int v1, int v2, float& s1, float& s2) {
+    if (!lk_any_lane_big((uint32_t)(v1 + (1 << 25)) | (uint32_t)(v2 + (1 << 25)))) {
+        wave_sum2_i32(v1, v2);
+        s1 = (float)v1; s2 = (float)v2;
+        return;
+    }
     int slo = (v1 & 1023) | ((v2 & 1023) << 16), sh1 = v1 >> 10, sh2 = v2 >> 10;
     wave_sum3_i32(slo, sh1, sh2);
     s1 = (float)((double)sh1 * 1024.0 + (double)(slo & 0xffff));
@@ -125,6 +135,11 @@ __device__ __forceinline__ void wave_sum_exact2(int v1, int v2, float& s1, float
 }
 // the same for three values: two registers of low parts, three of high parts
 __device__ __forceinline__ void wave_sum_exact3(int v1, int v2, int v3, float& s1, float& s2, float& s3) {
+    if (!lk_any_lane_big((uint32_t)(v1 + (1 << 25)) | (uint32_t)(v2 + (1 << 25)) | (uint32_t)(v3 + (1 << 25)))) {
+        wave_sum3_i32(v1, v2, v3);
+        s1 = (float)v1; s2 = (float)v2; s3 = (float)v3;
+        return;
+    }
     int slo = (v1 & 1023) | ((v2 & 1023) << 16), sh1 = v1 >> 10, sh2 = v2 >> 10;
     int slo3 = v3 & 1023, sh3 = v3 >> 10;
     wave_sum3_i32(slo, sh1, sh2);
