@@ -48,6 +48,17 @@ MEASURED_TRAFFIC = {
 }
 
 
+# Vector-ALU instructions per wavefront-lane-group ("wave instructions") per unit of work, from a rocprofv3 SQ_INSTS_VALU
+# / SQ_WAVES pass over this workload (profiles/r1_h_pmc_insts.txt).  These kernels are bound by vector-instruction issue,
+# not by HBM: one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
+MEASURED_VALU = {
+    ("cfg4", "lk_track"): (4160.0, "point"),                                   # one wave per point
+    ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
+    ("cfg4", "fast_grid"): ((346.1 * 53248 + 252.2 * 1600) / 64.0, "frame"),
+}
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0
+
+
 def level_sizes(w, h, max_level):
     out = []
     for _ in range(max_level + 1):
@@ -148,11 +159,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    # one rank per GPU; FT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path on a
+    # one-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("FT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -223,7 +241,7 @@ def main():
     lib.ft_profile(ctx2, 0)
 
     from feature_tracker_amd.sharding import reduce_run_totals
-    dt_max, (tracked_all, attempted_all) = reduce_run_totals(dt, [tracked, attempted], device=dev)
+    dt_max, (tracked_all, attempted_all) = reduce_run_totals(dt, [tracked, attempted], device=dev if backend == "nccl" else None)
 
     if rank == 0:
         # algorithmic bytes per launch group (= one step of all streams of this GPU)
@@ -256,9 +274,16 @@ def main():
         for name, e in per_kernel.items():
             m = MEASURED_TRAFFIC.get((args.workload, name)) if not args.host_frames else None
             e["hbm_traffic_bytes"] = m[0] * units[m[1]] if m else None
+            v = MEASURED_VALU.get((args.workload, name)) if not (args.host_frames or args.reject_outliers) else None
+            if v:
+                e["valu_wave_insts"] = v[0] * units[v[1]]
+                e["valu_issue_frac"] = e["valu_wave_insts"] / (e["avg_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S
         roofline = dict(kernel=kernel_names.get(dom), bound="hbm", achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=pk.get("frac_hbm_peak"), traffic=pk.get("hbm_traffic_bytes"),
-                        avg_launch_ms=pk.get("avg_ms"), algorithmic_bytes_per_launch=pk.get("algorithmic_bytes"))
+                        avg_launch_ms=pk.get("avg_ms"), algorithmic_bytes_per_launch=pk.get("algorithmic_bytes"),
+                        # what actually limits this kernel: vector-instruction issue (measured instruction count
+                        # over the issue capacity of the device during the launch)
+                        limiter="vector issue", valu_issue_frac=pk.get("valu_issue_frac"))
         out = {
             "metric": "tracked_features_per_sec", "value": tracked_all / dt_max, "unit": "features/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "weak",
