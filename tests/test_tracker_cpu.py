@@ -243,3 +243,21 @@ def test_feature_database_cpp(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "checks passed" in res.stdout
+
+
+def test_batch_threads_cpp_under_thread_sanitizer(tmp_path):
+    """Compiles tests/cpp/test_batch_threads.cpp with the host layer and the CPU checker's backend under
+    ThreadSanitizer and runs it: grouped, pipelined feeding equals the plain feed and no data race is reported."""
+    import subprocess
+    exe = str(tmp_path / "test_batch_threads")
+    src = [os.path.join(ROOT, "tests", "cpp", "test_batch_threads.cpp"), os.path.join(ROOT, "oracle", "oracle_backend.cpp"),
+           os.path.join(ROOT, "oracle", "ft_oracle.cpp"), os.path.join(ROOT, "feature_tracker_amd", "src", "ft_tracker_c.cpp"),
+           os.path.join(ROOT, "feature_tracker_amd", "src", "track", "TrackKLT.cpp"), os.path.join(ROOT, "feature_tracker_amd", "csrc", "ft_synth.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "feature_tracker_amd", "src"), "-I" + os.path.join(ROOT, "oracle"), "-o", exe] + src + ["-pthread"])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"))
+    if "FATAL: ThreadSanitizer" in res.stderr:
+        pytest.skip("ThreadSanitizer cannot start in this environment: " + res.stderr.strip().splitlines()[0])
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "checks passed" in res.stdout
+    assert "ThreadSanitizer: data race" not in res.stderr and "ThreadSanitizer: " not in res.stderr, res.stderr[:4000]
