@@ -40,11 +40,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 # HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
-# doubled as gfx950 requires; profiles/r1_f_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
+# doubled as gfx950 requires; profiles/r1_h_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
 MEASURED_TRAFFIC = {
-    ("cfg4", "lk_track"): (5817.3 + 19.9, "point"),
+    ("cfg4", "lk_track"): (5817.7 + 19.9, "point"),
     ("cfg4", "pyramid"): (363195.0 + 460832.0 + 126840.5 + 28800.0, "frame"),
-    ("cfg4", "fast_grid"): (373083.6 + 16715.2 + 6580.3 + 5017.0, "frame"),
+    ("cfg4", "fast_grid"): (372642.3 + 16712.3 + 5853.8 + 2709.2, "frame"),
 }
 
 
