@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: one 752x480 stream, 150 features, 21x21 window, 4 pyramid images, gyro seed
+    # the single-stream configuration: one 752x480 stream, 150 features, 21x21 window, 4 pyramid images, gyro seed
     "cfg2": dict(desc="1 x 752x480 stream, 150 features, maxLevel 3, win 21, gyro seed (latency-bound single stream)",
                  streams=1, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1)),
     # configs[2]: 1280x720, 2000 features, 4 levels, forward-backward
@@ -310,7 +310,7 @@ def main():
 
 
 def single_stream_latency(tracker, device, n=120):
-    """p50/p95 of one 752x480 frame, host pointer in -> tracked points readable on the host (BASELINE configs[1])."""
+    """p50/p95 of one 752x480 frame, host pointer in -> tracked points readable on the host (the single-stream configuration)."""
     wl = WORKLOADS["cfg2"]
     from feature_tracker_amd import synth
     q = synth.Sequence(wl["w"], wl["h"], n + 10, stream_id=99)
