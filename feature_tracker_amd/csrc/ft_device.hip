@@ -78,6 +78,12 @@ struct ft_ctx {
     size_t stage_bytes_per_slot = 0;
     std::vector<hipEvent_t> stage_done;
     std::vector<char> stage_busy;
+    uint8_t* stage_dev = nullptr;               // device-side address of `stage` (kernels read staged frames over the bus)
+    static constexpr int STAGE_EV_RING = 4;
+    hipEvent_t stage_batch_ev[STAGE_EV_RING] = {};   // recorded after a kernel that reads staged frames
+    int stage_batch_next = 0;
+    std::vector<int> stage_batch_idx;           // per slot: ring entry of the kernel still reading its staging, -1 = none
+                                                // (a reused entry holds a later event of the same queue: still correct)
 
     // LK staging
     uint8_t* lk_in_host = nullptr;  uint8_t* lk_in_dev = nullptr;  size_t lk_in_bytes = 0;
@@ -231,6 +237,7 @@ int deliver_pending(ft_ctx* c, uint64_t upto) {
 int sync_and_deliver(ft_ctx* c) {
     FT_HIP(c, hipStreamSynchronize(c->q));
     std::fill(c->stage_busy.begin(), c->stage_busy.end(), 0);
+    std::fill(c->stage_batch_idx.begin(), c->stage_batch_idx.end(), -1);
     prof_collect(c);
     return deliver_pending(c, ~0ull);
 }
@@ -282,6 +289,22 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
     }
     if (timed) prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
+    return FT_OK;
+}
+
+// copy a frame into the pinned staging buffer of a slot, tightly packed, once nothing on the device reads that buffer any more
+static int stage_rows(ft_ctx* c, int si, const uint8_t* host, int w, int h, size_t stride) {
+    if (c->stage_busy[si]) {   // a copy command from this staging buffer may still be in flight
+        FT_HIP(c, hipEventSynchronize(c->stage_done[si]));
+        c->stage_busy[si] = 0;
+    }
+    if (c->stage_batch_idx[si] >= 0) {   // ... or a kernel that reads it
+        FT_HIP(c, hipEventSynchronize(c->stage_batch_ev[c->stage_batch_idx[si]]));
+        c->stage_batch_idx[si] = -1;
+    }
+    uint8_t* st = c->stage + (size_t)si * c->stage_bytes_per_slot;
+    if (stride == (size_t)w) memcpy(st, host, (size_t)w * h);
+    else for (int y = 0; y < h; y++) memcpy(st + (size_t)y * w, host + (size_t)y * stride, (size_t)w);
     return FT_OK;
 }
 
@@ -355,8 +378,16 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->stage_bytes_per_slot = align_up((size_t)lim->max_width * lim->max_height, 4096);
     if (hipHostMalloc(&p, c->stage_bytes_per_slot * n_slots_total, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->stage = (uint8_t*)p;
+    {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(FT_E_HIP);
+        c->stage_dev = (uint8_t*)dp;
+    }
     c->stage_done.resize(n_slots_total, nullptr);
     c->stage_busy.assign(n_slots_total, 0);
+    c->stage_batch_idx.assign(n_slots_total, -1);
+    for (auto& e : c->stage_batch_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(FT_E_HIP);
     for (auto& e : c->stage_done)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(FT_E_HIP);
 
@@ -423,6 +454,7 @@ void ft_ctx_destroy(ft_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->q) (void)hipStreamSynchronize(c->q);
     for (auto& e : c->stage_done) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->stage_batch_ev) if (e) (void)hipEventDestroy(e);
     for (auto& ep : c->ev_inflight) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->region_a) (void)hipEventDestroy(c->region_a);
@@ -453,12 +485,8 @@ int ft_upload(ft_ctx* c, int stream, int slot, const uint8_t* host, int w, int h
     if (si < 0) return FT_E_INVALID;
     if (w > c->lim.max_width || h > c->lim.max_height) return FT_E_LIMIT;
     FT_HIP(c, hipSetDevice(c->device));
-    if (c->stage_busy[si]) {   // a previous upload from this staging buffer may still be in flight
-        FT_HIP(c, hipEventSynchronize(c->stage_done[si]));
-        c->stage_busy[si] = 0;
-    }
+    { const int rc = stage_rows(c, si, host, w, h, stride); if (rc) return rc; }
     uint8_t* st = c->stage + (size_t)si * c->stage_bytes_per_slot;
-    for (int y = 0; y < h; y++) memcpy(st + (size_t)y * w, host + (size_t)y * stride, (size_t)w);
     uint8_t* dst = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[0].img_off;
     FT_HIP(c, hipMemcpy2DAsync(dst, c->arena.lv[0].img_pitch, st, (size_t)w, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->q));
     FT_HIP(c, hipEventRecord(c->stage_done[si], c->q));
@@ -515,28 +543,18 @@ int ft_build_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, int
     return FT_OK;
 }
 
-int ft_set_frames_device_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride,
-                                 int max_level, int win_w, int win_h, int* achieved) {
-    if (!c || n < 1 || n > FT_MAX_BATCH || !streams || !slots || !dev || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
-    if (max_level < 0 || win_w < 3 || win_h < 3) return FT_E_INVALID;
-    if (w > c->lim.max_width || h > c->lim.max_height || max_level + 1 > c->lim.max_levels) return FT_E_LIMIT;
-    ImgList L;
-    L.n = n;
-    for (int i = 0; i < n; i++) {
-        const int si = slot_index(c, streams[i], slots[i]);
-        if (si < 0 || !dev[i]) return FT_E_INVALID;
-        L.idx[i] = si;
-    }
-    FT_HIP(c, hipSetDevice(c->device));
+// level 0 and the pyramid of n frames readable by the device at src[i] (row stride `stride`)
+static int frames_to_pyramid(ft_ctx* c, const ImgList& L, int n, const uint8_t* const* src, int w, int h, size_t stride, int max_level,
+                             int win_w, int win_h, int* achieved) {
     const int top = achieved_level(w, h, win_w, win_h, max_level);
-    // level 0 and level 1 come out of one pass over the caller's frames
+    // level 0 and level 1 come out of one pass over the frames
     EventPair ep;
     prof_begin(c, 0, ep);
     const int tiles = ((w + LV_TX - 1) / LV_TX) * ((h + LV_TY - 1) / LV_TY);
     for (int first = 0; first < n; first += FRAME_PTRS) {
         const int m = std::min(FRAME_PTRS, n - first);
         FramePtrs F{};
-        for (int i = 0; i < m; i++) F.p[i] = static_cast<const uint8_t*>(dev[first + i]);
+        for (int i = 0; i < m; i++) F.p[i] = src[first + i];
         hipLaunchKernelGGL((level_kernel<true>), dim3(xcd_grid(tiles * m)), dim3(256), 0, c->q, c->arena, L, F, first, 0, w, h,
                            (uint64_t)stride, 0, top > 0 ? 1 : 0);
     }
@@ -550,6 +568,57 @@ int ft_set_frames_device_pyramid(ft_ctx* c, int n, const int* streams, const int
         c->slots[L.idx[i]] = SlotState{w, h, top + 1, 0};
         if (achieved) achieved[i] = top;
     }
+    return FT_OK;
+}
+
+int ft_set_frames_device_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride,
+                                 int max_level, int win_w, int win_h, int* achieved) {
+    if (!c || n < 1 || n > FT_MAX_BATCH || !streams || !slots || !dev || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
+    if (max_level < 0 || win_w < 3 || win_h < 3) return FT_E_INVALID;
+    if (w > c->lim.max_width || h > c->lim.max_height || max_level + 1 > c->lim.max_levels) return FT_E_LIMIT;
+    ImgList L;
+    L.n = n;
+    const uint8_t* src[FT_MAX_BATCH];
+    for (int i = 0; i < n; i++) {
+        const int si = slot_index(c, streams[i], slots[i]);
+        if (si < 0 || !dev[i]) return FT_E_INVALID;
+        L.idx[i] = si;
+        src[i] = static_cast<const uint8_t*>(dev[i]);
+    }
+    FT_HIP(c, hipSetDevice(c->device));
+    return frames_to_pyramid(c, L, n, src, w, h, stride, max_level, win_w, win_h, achieved);
+}
+
+int ft_stage_frame(ft_ctx* c, int stream, int slot, const uint8_t* host, int w, int h, size_t stride) {
+    if (!c || !host || w < 1 || h < 1 || stride < (size_t)w) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    if (si < 0) return FT_E_INVALID;
+    if (w > c->lim.max_width || h > c->lim.max_height) return FT_E_LIMIT;
+    return stage_rows(c, si, host, w, h, stride);
+}
+
+int ft_set_frames_staged_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, int w, int h, int max_level, int win_w, int win_h,
+                                 int* achieved) {
+    if (!c || n < 1 || n > FT_MAX_BATCH || !streams || !slots || w < 1 || h < 1) return FT_E_INVALID;
+    if (max_level < 0 || win_w < 3 || win_h < 3) return FT_E_INVALID;
+    if (w > c->lim.max_width || h > c->lim.max_height || max_level + 1 > c->lim.max_levels) return FT_E_LIMIT;
+    ImgList L;
+    L.n = n;
+    const uint8_t* src[FT_MAX_BATCH];
+    for (int i = 0; i < n; i++) {
+        const int si = slot_index(c, streams[i], slots[i]);
+        if (si < 0) return FT_E_INVALID;
+        L.idx[i] = si;
+        src[i] = c->stage_dev + (size_t)si * c->stage_bytes_per_slot;
+    }
+    FT_HIP(c, hipSetDevice(c->device));
+    const int rc = frames_to_pyramid(c, L, n, src, w, h, (size_t)w, max_level, win_w, win_h, achieved);
+    if (rc) return rc;
+    // the staging buffers are free again once the level-0 pass has read them
+    const int e = c->stage_batch_next;
+    c->stage_batch_next = (e + 1) % ft_ctx::STAGE_EV_RING;
+    FT_HIP(c, hipEventRecord(c->stage_batch_ev[e], c->q));
+    for (int i = 0; i < n; i++) c->stage_batch_idx[L.idx[i]] = e;
     return FT_OK;
 }
 

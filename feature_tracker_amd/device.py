@@ -66,7 +66,7 @@ class ft_kernel_time(C.Structure):
 # every symbol include/ft_device.h declares
 SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device",
            "ft_set_frames_device_pyramid", "ft_build_pyramid",
-           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_match_descriptors", "ft_fast_grid", "ft_fast_grid_async",
+           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_match_descriptors", "ft_stage_frame", "ft_set_frames_staged_pyramid", "ft_fast_grid", "ft_fast_grid_async",
            "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
            "ft_last_hip_error", "ft_device_count"]
@@ -112,6 +112,8 @@ def load_library():
     lib.ft_build_gradients.argtypes = [vp, C.c_int, ip, ip]
     lib.ft_lk_track.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
     lib.ft_lk_track_async.argtypes = [vp, C.c_int, C.POINTER(ft_lk_job), C.POINTER(ft_lk_params)]
+    lib.ft_stage_frame.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t]
+    lib.ft_set_frames_staged_pyramid.argtypes = [vp, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip]
     lib.ft_match_descriptors.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.POINTER(ft_match), C.c_int, ip]
     lib.ft_reject_outliers.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
     lib.ft_reject_outliers_async.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
@@ -231,6 +233,21 @@ class DeviceContext:
         ach = np.zeros(len(s), dtype=np.int32)
         self._check(self.lib.ft_set_frames_device_pyramid(self._ctx, len(s), sp, lp, ptrs, w, h, stride, max_level, win_w, win_h,
                                                           ach.ctypes.data_as(C.POINTER(C.c_int))), "ft_set_frames_device_pyramid")
+        return ach
+
+    def set_frames_host_pyramid(self, streams, slots, frames, max_level=3, win=15):
+        """Frames in host memory (list of (h, w) uint8 arrays of one size): staged into pinned memory, then level 0 and
+        the pyramids in one pass that reads the staging over the bus (no copy command)."""
+        s, sp = _ints(streams)
+        l, lp = _ints(slots)
+        win_w, win_h = (win, win) if np.isscalar(win) else win
+        h, w = frames[0].shape
+        for st, sl, f in zip(s, l, frames):
+            f = np.ascontiguousarray(f, dtype=np.uint8)
+            self._check(self.lib.ft_stage_frame(self._ctx, int(st), int(sl), f.ctypes.data, w, h, f.strides[0]), "ft_stage_frame")
+        ach = np.zeros(len(s), dtype=np.int32)
+        self._check(self.lib.ft_set_frames_staged_pyramid(self._ctx, len(s), sp, lp, w, h, max_level, win_w, win_h,
+                                                          ach.ctypes.data_as(C.POINTER(C.c_int))), "ft_set_frames_staged_pyramid")
         return ach
 
     def build_pyramid(self, streams, slots, max_level=3, win=15, with_gradients=True):

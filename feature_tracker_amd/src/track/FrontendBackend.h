@@ -17,6 +17,11 @@ public:
     // set_frames_device + build_pyramid(with_gradients = 0) as one pass over the frames
     virtual int set_frames_device_pyramid(int n, const int* streams, const int* slots, const void* const* dev, int w, int h, size_t stride,
                                           int max_level, int win_w, int win_h, int* achieved) = 0;
+    // frames in host memory without a copy command: stage_frame copies one frame into the backend's staging (different
+    // slots may be staged from different threads at once), set_frames_staged_pyramid turns the staged frames into pyramids
+    virtual int stage_frame(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) = 0;
+    virtual int set_frames_staged_pyramid(int n, const int* streams, const int* slots, int w, int h, int max_level, int win_w, int win_h,
+                                          int* achieved) = 0;
     virtual int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
                               int with_gradients, int* achieved) = 0;
     virtual int lk_track_async(int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) = 0;

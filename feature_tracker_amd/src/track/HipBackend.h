@@ -27,6 +27,13 @@ public:
                                   int max_level, int win_w, int win_h, int* achieved) override {
         return ft_set_frames_device_pyramid(ctx_, n, streams, slots, dev, w, h, stride, max_level, win_w, win_h, achieved);
     }
+    int stage_frame(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) override {
+        return ft_stage_frame(ctx_, stream, slot, host, w, h, stride);
+    }
+    int set_frames_staged_pyramid(int n, const int* streams, const int* slots, int w, int h, int max_level, int win_w, int win_h,
+                                  int* achieved) override {
+        return ft_set_frames_staged_pyramid(ctx_, n, streams, slots, w, h, max_level, win_w, win_h, achieved);
+    }
     int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h, int with_gradients,
                       int* achieved) override {
         return ft_build_pyramid(ctx_, n, streams, slots, max_level, win_w, win_h, with_gradients, achieved);

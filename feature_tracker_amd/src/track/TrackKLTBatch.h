@@ -297,9 +297,10 @@ private:
         TrackKLT& t0 = *trackers[0];
         int rc = FT_OK;
         front_streams.resize(S);
-        bool all_dev = true;
+        bool all_dev = true, all_host = true;
         for (int s = 0; s < S; s++) {
             front_streams[s] = s;   // tracker s owns backend stream s (stream_base = s, camera 0)
+            all_host &= frames[s].dev == nullptr && frames[s].host != nullptr && frames[s].cols == frames[0].cols && frames[s].rows == frames[0].rows;
             all_dev &= frames[s].dev != nullptr && frames[s].cols == frames[0].cols && frames[s].rows == frames[0].rows && frames[s].step == frames[0].step;
         }
         if (all_dev) {   // frames already in HBM: ingest and pyramids in one pass over the frames
@@ -308,6 +309,15 @@ private:
             if (lap) (*lap)(ST_INGEST);
             if ((rc = be->set_frames_device_pyramid(S, front_streams.data(), slots.data(), dev_ptrs.data(), frames[0].cols, frames[0].rows,
                                                     frames[0].step, t0.max_level(), t0.window(), t0.window(), nullptr)) != FT_OK) return rc;
+        } else if (all_host) {   // frames in host memory: staged by this thread and its helpers, then one pass over the staging
+            stage_rc.assign(S, FT_OK);
+            pool->parallel_for(S, [&](int s) {
+                stage_rc[s] = be->stage_frame(front_streams[s], slots[s], frames[s].host, frames[s].cols, frames[s].rows, frames[s].step);
+            });
+            for (int s = 0; s < S; s++) if (stage_rc[s] != FT_OK) return stage_rc[s];
+            if (lap) (*lap)(ST_INGEST);
+            if ((rc = be->set_frames_staged_pyramid(S, front_streams.data(), slots.data(), frames[0].cols, frames[0].rows, t0.max_level(),
+                                                    t0.window(), t0.window(), nullptr)) != FT_OK) return rc;
         } else {
             for (int s = 0; s < S; s++) {
                 const FrameSource& f = frames[s];
@@ -342,7 +352,7 @@ private:
     bool staged = false;
     std::vector<double> staged_ts;
     std::vector<FrameSource> staged_frames;
-    std::vector<int> staged_slots, front_streams;
+    std::vector<int> staged_slots, front_streams, stage_rc;
     uint64_t wait_token = 0;
     std::vector<std::unique_ptr<TrackKLT>> trackers;
     std::vector<TrackKLT::MonoPlan> plans, db_plans;

@@ -148,6 +148,16 @@ int ft_set_frames_device(ft_ctx* ctx, int n, const int* streams, const int* slot
 int ft_set_frames_device_pyramid(ft_ctx* ctx, int n, const int* streams, const int* slots, const void* const* dev, int w, int h,
                                  size_t stride, int max_level, int win_w, int win_h, int* achieved);
 
+/* Frames in host memory, for many streams at once and without a copy command: ft_stage_frame copies one frame into the
+ * context's pinned staging buffer of (stream, slot) on the calling thread (it first waits until nothing on the device
+ * reads that buffer any more; calls for different slots may run on different threads at the same time), and
+ * ft_set_frames_staged_pyramid builds level 0 and the pyramid of the staged frames in one pass that reads the staging
+ * over the bus.  Replaces, like ft_upload + ft_build_pyramid, img.clone() and cv::buildOpticalFlowPyramid
+ * (src/track/TrackKLT.cpp:46-56). */
+int ft_stage_frame(ft_ctx* ctx, int stream, int slot, const uint8_t* host, int w, int h, size_t stride);
+int ft_set_frames_staged_pyramid(ft_ctx* ctx, int n, const int* streams, const int* slots, int w, int h, int max_level, int win_w,
+                                 int win_h, int* achieved);
+
 /* Levels 1..max_level by pyrDown and, if with_gradients, Scharr (Ix,Iy) of every level, for n images in one
  * launch per level.  achieved[i] (optional) receives the top level index after the early-stop rule of
  * buildOpticalFlowPyramid (stop when the next level would not exceed the window). Asynchronous. */

@@ -62,6 +62,13 @@ public:
         const int rc = set_frames_device(n, streams, slots, dev, w, h, stride);
         return rc != FT_OK ? rc : build_pyramid(n, streams, slots, max_level, win_w, win_h, 0, achieved);
     }
+    int stage_frame(int stream, int slot, const uint8_t* host, int w, int h, size_t stride) override {
+        return upload(stream, slot, host, w, h, stride);   // slots are separate objects: safe from several threads
+    }
+    int set_frames_staged_pyramid(int n, const int* streams, const int* slots, int, int, int max_level, int win_w, int win_h,
+                                  int* achieved) override {
+        return build_pyramid(n, streams, slots, max_level, win_w, win_h, 0, achieved);
+    }
     int build_pyramid(int n, const int* streams, const int* slots, int max_level, int win_w, int win_h, int, int* achieved) override {
         for (int i = 0; i < n; i++) { Slot* S = at(streams[i], slots[i]); if (!S || S->img.empty()) return FT_E_STATE; }
         parallel_for(n, g_threads, [&](int i) {

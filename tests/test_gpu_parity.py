@@ -100,6 +100,21 @@ def test_ingest_pyramid_single_pass_bit_exact(dev, shape, win, max_level, pad):
                 assert np.array_equal(ctx.download_level(i, 1 - i, l), ref.level(l)), f"image {i} level {l}"
 
 
+def test_staged_host_frames_pyramid_bit_exact(dev):
+    """Host frames through the pinned staging read directly by the level-0 pass; a second round reuses the staging
+    buffers (the staging call waits for the pass that still reads them)."""
+    h, w = 479, 751
+    with _ctx(dev, 752, 480, n_streams=3) as ctx:
+        for rnd in range(3):
+            frames = [synth.texture(w, h, seed=200 + 3 * rnd + i) for i in range(3)]
+            ach = ctx.set_frames_host_pyramid([0, 1, 2], [rnd % 2] * 3, frames, max_level=3, win=21)
+            for i, f in enumerate(frames):
+                ref = O.Pyramid(f, 21, 3)
+                assert ach[i] == ref.levels - 1
+                for l in range(ref.levels):
+                    assert np.array_equal(ctx.download_level(i, rnd % 2, l), ref.level(l)), f"round {rnd} image {i} level {l}"
+
+
 def _compare_lk(gpu, ref, min_agree=STATUS_AGREE):
     g_xy, g_st, g_err = gpu[:3]
     r_xy, r_st, r_err = ref[:3]
