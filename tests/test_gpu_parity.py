@@ -248,6 +248,66 @@ def test_fast_grid_batched_and_plateaus(dev):
         assert np.array_equal(out[i, : n_out[i]], ref)
 
 
+def test_full_size_4k_frame_10k_features(dev):
+    """The largest configuration (3840x2160, up to 10 000 features, maxLevel 5, grid 26x15) against the CPU checker."""
+    w, h = 3840, 2160
+    prev, nxt = synth.shifted_pair(w, h, dx=5, dy=-3, seed=500)
+    rp, rn = O.Pyramid(prev, 21, 5), O.Pyramid(nxt, 21, 5)
+    with _ctx(dev, w, h, n_streams=1, max_levels=6, max_points=12000, max_grid_cells=26 * 15, max_per_cell=32) as ctx:
+        ctx.set_frames_host_pyramid([0], [0], [prev], max_level=5, win=21)
+        ctx.set_frames_host_pyramid([0], [1], [nxt], max_level=5, win=21)
+        for l in range(rp.levels):
+            assert np.array_equal(ctx.download_level(0, 0, l), rp.level(l)), f"level {l}"
+        kp, n_kp, _ = ctx.fast_grid([0], [0], 8, 26, 15, 10000 // 390 + 1)
+        ref = O.grid_fast(prev, 10000, 26, 15, 8, n_threads=8)
+        assert np.array_equal(kp[0, : n_kp[0]], ref) and n_kp[0] > 2000
+        pts = np.ascontiguousarray(ref[:10000, :2])
+        xy, st, er = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=21, max_level=5))[0]
+    r_xy, r_st, r_er = O.lk_track(rp, rn, pts, win=21, max_level=5, n_threads=8)
+    assert np.array_equal(st, r_st) and st.mean() > 0.95
+    ok = st == 1
+    assert np.array_equal(xy[ok], r_xy[ok])
+    assert np.percentile(np.abs((xy[ok] - pts[ok]) - [5, -3]), 99) < 0.5   # and the flow is the known displacement
+
+
+def test_ragged_empty_and_full_batches(dev):
+    """The shapes a caller can throw at the batched entry points: a full batch of 256 small images, jobs with no
+    points, one point, and only lost points next to ordinary ones, a flat image without any corner."""
+    n_img, w, h = 256, 96, 64
+    rng = np.random.default_rng(11)
+    prevs = [synth.texture(w, h, seed=300 + i, n_shapes=60) for i in range(n_img)]
+    prevs[7] = np.full((h, w), 90, np.uint8)                                 # no texture at all
+    nexts = [np.roll(p, (1, 2), axis=(0, 1)) for p in prevs]
+    with _ctx(dev, w, h, n_streams=n_img, max_levels=3, max_points=4000, max_grid_cells=6, max_per_cell=8) as ctx:
+        ids = list(range(n_img))
+        ctx.set_frames_host_pyramid(ids, [0] * n_img, prevs, max_level=2, win=9)
+        ctx.set_frames_host_pyramid(ids, [1] * n_img, nexts, max_level=2, win=9)
+        kp, n_kp, _ = ctx.fast_grid(ids, [0] * n_img, 20, 3, 2, 4)
+        for i in (0, 7, 100, 255):
+            assert np.array_equal(kp[i, : n_kp[i]], O.grid_fast(prevs[i], 6 * 4 - 1, 3, 2, 20))
+        assert n_kp[7] == 0
+        jobs, counts = [], []
+        for i in range(n_img):
+            m = [0, 1, 12, 5][i % 4]
+            pts = synth.random_points(w, h, m, seed=400 + i, border=6) if i % 8 != 3 else np.full((m, 2), -500.0, np.float32)
+            jobs.append(dict(prev=(i, 0), next=(i, 1), prev_xy=pts))
+            counts.append(m)
+        outs = ctx.lk_track(jobs, dev.LKParams(win=9, max_level=2))
+        for i in (0, 1, 2, 3, 7, 11, 254, 255):
+            xy, st, er = outs[i]
+            assert len(st) == counts[i]
+            if counts[i] == 0:
+                continue
+            r_xy, r_st, r_er = O.lk_track(O.Pyramid(prevs[i], 9, 2), O.Pyramid(nexts[i], 9, 2), jobs[i]["prev_xy"], win=9, max_level=2)
+            assert np.array_equal(st, r_st)
+            ok = st == 1
+            assert np.array_equal(xy[ok], r_xy[ok])
+            if i % 8 == 3:
+                assert not st.any()                                          # far outside the frame: all lost
+        with pytest.raises(dev.FtError):                                     # one image more than a batch may hold
+            ctx.fast_grid(ids + [0], [0] * (n_img + 1), 20, 3, 2, 4)
+
+
 CALIBS = [np.array([458.7, 457.3, 367.2, 248.4, -0.28, 0.074, 2e-4, 2e-5]), np.array([600., 600., 376., 240., 0, 0, 0, 0])]
 
 
