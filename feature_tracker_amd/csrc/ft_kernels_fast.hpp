@@ -72,13 +72,14 @@ __device__ inline uint32_t fast_key(int score, int ly, int lx) {
     return ((uint32_t)score << 24) | ((uint32_t)(4095 - ly) << 12) | (uint32_t)(4095 - lx);
 }
 
-// Detector tile geometry.  A workgroup reports the corners of a 60x30 output region whose first column is 2 mod 4
-// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x32
-// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 30: exactly 16 dwords x 32
-// rows = two 4-pixel tasks per thread, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the
+// Detector tile geometry.  A workgroup reports the corners of a 60x62 output region whose first column is 2 mod 4
+// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x64
+// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 62: exactly 16 dwords x 64
+// rows = four 4-pixel tasks per thread, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the
 // radius of the circle and is staged from column CX0 - 8 in 8-byte groups.
-constexpr int FD_OW = 60, FD_OH = 30;            // output region
-constexpr int FD_CW = 64, FD_CH = 32;            // score container
+constexpr int FD_ROUNDS = 4;                     // 16 container rows per round of the 256 threads
+constexpr int FD_OW = 60, FD_OH = 16 * FD_ROUNDS - 2;   // output region
+constexpr int FD_CW = 64, FD_CH = 16 * FD_ROUNDS;       // score container
 constexpr int FD_PPITCH = 80;                    // pixel tile row: columns CX0-8 .. CX0+71
 constexpr int FD_PROWS = FD_CH + 6;              // rows OY-4 .. OY+33
 constexpr int FD_GROUPS = FD_PPITCH / 8;         // 8-byte groups per pixel row
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     const uint8_t* __restrict__ img = level_img(A, slot, 0);
     const uint32_t pitch = A.lv[0].img_pitch;
 
-    // ---- stage pixels: a wavefront load covers 6 rows x 10 groups of 8 bytes; 2 rounds x 4 waves = 48 rows.
+    // ---- stage pixels: a wavefront load covers 6 rows x 10 groups of 8 bytes; 3 rounds x 4 waves = 72 rows.
     //      Rows are clamped into the image and the group left of the image is clamped to column 0: only insets are
     //      ever evaluated, and an inset pixel's circle lies inside the image.  Columns past the row end read on
     //      into the next row of the plane (never used). ----
@@ -118,21 +119,23 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
         const int lane = t & 63, wv = t >> 6;
         const int rg = lane / FD_GROUPS, c8 = lane - rg * FD_GROUPS;
         const int gx = max(CX0 - 8 + 8 * c8, 0);
-        uint2 v[2];
+        constexpr int SR = (FD_PROWS + 23) / 24;   // staging rounds: 4 waves x 6 rows each
+        uint2 v[SR];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < SR; k++) {
             const int row = min(wv * 6 + rg + 24 * k, FD_PROWS - 1);
             const int gy = min(max(OY - 4 + row, 0), G.h - 1);
             const FdU2Unaligned u = *reinterpret_cast<const FdU2Unaligned*>(img + ((uint32_t)gy * pitch + (uint32_t)gx));
             v[k] = make_uint2(u.a, u.b);
         }
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < SR; k++) {
             const int row = wv * 6 + rg + 24 * k;
             if (lane < 6 * FD_GROUPS && row < FD_PROWS) *reinterpret_cast<uint2*>(&pix[row * FD_PPITCH + 8 * c8]) = v[k];
         }
     }
-    reinterpret_cast<uint2*>(sc)[t] = make_uint2(0u, 0u);   // 256 threads x 8 bytes = the whole score tile
+#pragma unroll
+    for (int k = 0; k < FD_CH * FD_CW / 2048; k++) reinterpret_cast<uint2*>(sc)[t + 256 * k] = make_uint2(0u, 0u);   // the whole score tile
     if (t == 0) list_n = 0;
     // cell membership is separable: one division per column and per row of the container instead of two per pixel
     if (t < FD_CW) {
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     const uint32_t colbytes = *reinterpret_cast<const uint32_t*>(&col_ok[4 * d]);   // one byte per column
     const uint32_t colbits = (colbytes & 1u) | ((colbytes >> 7) & 2u) | ((colbytes >> 14) & 4u) | ((colbytes >> 21) & 8u);
 #pragma unroll
-    for (int round = 0; round < 2; round++) {
+    for (int round = 0; round < FD_ROUNDS; round++) {
         const int r = (t >> 4) + 16 * round;                                 // container row
         uint32_t hits = 0;
         if (colbits != 0 && row_ok[r]) {
@@ -208,10 +211,10 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     }
     __syncthreads();
 
-    // ---- strict 3x3 maxima of the output region (container rows 1..30, columns 2..61) -> per-cell candidate lists ----
+    // ---- strict 3x3 maxima of the output region (container rows 1..62, columns 2..61) -> per-cell candidate lists ----
     const int cells = G.ct_cols * G.ct_rows;
 #pragma unroll
-    for (int round = 0; round < 2; round++) {
+    for (int round = 0; round < FD_ROUNDS; round++) {
         const int r = 1 + (t >> 4) + 16 * round;
         if (r > FD_OH) continue;
         const uint32_t S4 = *reinterpret_cast<const uint32_t*>(&sc[r * FD_CW + 4 * d]);
