@@ -270,6 +270,46 @@ def test_full_size_4k_frame_10k_features(dev):
     assert np.percentile(np.abs((xy[ok] - pts[ok]) - [5, -3]), 99) < 0.5   # and the flow is the known displacement
 
 
+def test_properties_at_the_benchmark_batch_size(dev):
+    """64 streams of 752x480 in one call, checked through properties that need no reference: detector output ranked and
+    inside the cell insets, tracking a frame against itself is the identity with zero residual, and tracking against
+    an integer-shifted copy returns exactly that shift for every feature whose window stays inside both frames."""
+    S, w, h = 64, 752, 480
+    big = [synth.texture(w + 16, h + 16, seed=700 + s) for s in range(S)]
+    a = [np.ascontiguousarray(b[8:8 + h, 8:8 + w]) for b in big]
+    sh = [np.ascontiguousarray(b[8 - 2:8 - 2 + h, 8 + 3:8 + 3 + w]) for b in big]      # content moves by (-3, +2)
+    ids = list(range(S))
+    with _ctx(dev, w, h, n_streams=S, max_levels=4, max_points=S * 200, max_grid_cells=25, max_per_cell=8) as ctx:
+        ctx.set_frames_host_pyramid(ids, [0] * S, a, max_level=3, win=21)
+        ctx.set_frames_host_pyramid(ids, [1] * S, sh, max_level=3, win=21)
+        kp, n_kp, _ = ctx.fast_grid(ids, [0] * S, 20, 5, 5, 7)
+        sx, sy = w // 5, h // 5
+        for s in range(S):
+            k = kp[s, : n_kp[s]]
+            assert 0 < len(k) <= 25 * 7
+            cell = (k[:, 1] // sy).astype(int) * 5 + (k[:, 0] // sx).astype(int)
+            assert np.all(np.diff(cell) >= 0)                                            # concatenated by cell index
+            same = np.diff(cell) == 0
+            assert np.all(np.diff(k[:, 2])[same] <= 0)                                   # ranked inside a cell
+            lx, ly = k[:, 0] % sx, k[:, 1] % sy
+            assert lx.min() >= 3 and lx.max() < sx - 3 and ly.min() >= 3 and ly.max() < sy - 3 and k[:, 2].min() >= 20
+        jobs_id = [dict(prev=(s, 0), next=(s, 0), prev_xy=kp[s, : n_kp[s], :2]) for s in range(S)]
+        jobs_sh = [dict(prev=(s, 0), next=(s, 1), prev_xy=kp[s, : n_kp[s], :2]) for s in range(S)]
+        out_id = ctx.lk_track(jobs_id, dev.LKParams(win=21, max_level=3))
+        out_sh = ctx.lk_track(jobs_sh, dev.LKParams(win=21, max_level=3))
+    n_inner = 0
+    for s in range(S):
+        p = kp[s, : n_kp[s], :2]
+        xy, st, er = out_id[s]
+        assert st.all() and np.array_equal(xy, p) and not er.any()
+        xy, st, er = out_sh[s]
+        inner = (p[:, 0] > 40) & (p[:, 0] < w - 40) & (p[:, 1] > 40) & (p[:, 1] < h - 40)
+        assert st[inner].all()
+        assert np.abs(xy[inner] - p[inner] - [-3, 2]).max() < 0.02 and er[inner].max() < 0.5
+        n_inner += int(inner.sum())
+    assert n_inner > S * 60
+
+
 def test_ragged_empty_and_full_batches(dev):
     """The shapes a caller can throw at the batched entry points: a full batch of 256 small images, jobs with no
     points, one point, and only lost points next to ordinary ones, a flat image without any corner."""
