@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 MEASURED_TRAFFIC = {
     ("cfg4", "lk_track"): (5817.7 + 19.9, "point"),
     ("cfg4", "pyramid"): (363195.0 + 460832.0 + 126840.5 + 28800.0, "frame"),
-    ("cfg4", "fast_grid"): (372642.3 + 16712.3 + 5853.8 + 2709.2, "frame"),
+    ("cfg4", "fast_grid"): (374958.1 + 16713.3 + 5852.2 + 2709.2, "frame"),
 }
 
 
@@ -54,7 +54,7 @@ MEASURED_TRAFFIC = {
 MEASURED_VALU = {
     ("cfg4", "lk_track"): (4160.0, "point"),                                   # one wave per point
     ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
-    ("cfg4", "fast_grid"): ((346.1 * 53248 + 252.2 * 1600) / 64.0, "frame"),
+    ("cfg4", "fast_grid"): ((610.0 * 26624 + 252.2 * 1600) / 64.0, "frame"),
 }
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0
 
