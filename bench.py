@@ -301,7 +301,7 @@ def main():
         }
         if not args.no_latency:
             out["latency"] = single_stream_latency(tracker, local_rank)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on a single-GPU run only
             out["cpu_baseline"] = cpu_baseline(wl, seqs, threads)
         print(json.dumps(out), flush=True)
     if distributed:
