@@ -158,15 +158,17 @@ int ft_stage_frame(ft_ctx* ctx, int stream, int slot, const uint8_t* host, int w
 int ft_set_frames_staged_pyramid(ft_ctx* ctx, int n, const int* streams, const int* slots, int w, int h, int max_level, int win_w,
                                  int win_h, int* achieved);
 
-/* Levels 1..max_level by pyrDown and, if with_gradients, Scharr (Ix,Iy) of every level, for n images in one
- * launch per level.  achieved[i] (optional) receives the top level index after the early-stop rule of
+/* cv::buildOpticalFlowPyramid(img, pyr, win_size, pyr_levels) of src/track/TrackKLT.cpp:51-56 for n images at once:
+ * levels 1..max_level by pyrDown and, if with_gradients, Scharr (Ix,Iy) of every level (calcSharrDeriv), one launch
+ * per level.  achieved[i] (optional) receives the top level index after the early-stop rule of
  * buildOpticalFlowPyramid (stop when the next level would not exceed the window). Asynchronous. */
 int ft_build_pyramid(ft_ctx* ctx, int n, const int* streams, const int* slots, int max_level, int win_w, int win_h,
                      int with_gradients, int* achieved);
 /* Scharr gradients for pyramids that were built without them. Asynchronous. */
 int ft_build_gradients(ft_ctx* ctx, int n, const int* streams, const int* slots);
 
-/* Pyramidal LK for n_jobs image pairs in one launch.  ft_lk_track returns with the outputs written;
+/* cv::calcOpticalFlowPyrLK(pyr0, pyr1, pts0, pts1, status, err, win, maxLevel, term_crit, flags) of
+ * src/track/TrackKLT.cpp:306 and :402, for n_jobs image pairs in one launch.  ft_lk_track returns with the outputs written;
  * ft_lk_track_async returns after enqueueing and the outputs are written by the next ft_sync. */
 int ft_lk_track(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm);
 int ft_lk_track_async(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm);
@@ -180,7 +182,8 @@ int ft_lk_track_async(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_l
 int ft_reject_outliers(ft_ctx* ctx, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed);
 int ft_reject_outliers_async(ft_ctx* ctx, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed);
 
-/* Per-cell FAST-9/16 + 3x3 NMS + per-cell top `per_cell` by (response desc, y asc, x asc), for n images.
+/* Grider_FAST::perform_griding (src/track/Grider_FAST.h:76-132) for n images: per-cell cv::FAST(roi, threshold, true) =
+ * FAST-9/16 + 3x3 NMS, then the per-cell top `per_cell` by (response desc, y asc, x asc).
  * Image i writes at most `cap` keypoints at out + i*cap, cells in index order, and its count to n_out[i].
  * cell_counts (optional, n*cells) receives the number of NMS survivors per cell before truncation. */
 int ft_fast_grid(ft_ctx* ctx, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
@@ -188,7 +191,6 @@ int ft_fast_grid(ft_ctx* ctx, int n, const int* streams, const int* slots, int t
 int ft_fast_grid_async(ft_ctx* ctx, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
                        int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts);
 
-/* H = K*R*K^-1 (host, float32; K4 = fx,fy,cx,cy) and the device point warp p' = pi(H*[p;1]). */
 /* Matching of two sets of 256-bit binary descriptors (ORB rows, 32 bytes each) as TrackDescriptor::robust_match does
  * it before its RANSAC (src/track/TrackDescriptor.cpp:249-265, :309-354): the two nearest neighbours of every
  * descriptor in the other set, both ways (cv::BFMatcher(NORM_HAMMING).knnMatch(…, 2); equal distances: the lower
@@ -200,6 +202,8 @@ int ft_fast_grid_async(ft_ctx* ctx, int n, const int* streams, const int* slots,
 int ft_match_descriptors(ft_ctx* ctx, const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio,
                          ft_match* out, int cap, int* n_out);
 
+/* H = K*R*K^-1 (host, float32; K4 = fx,fy,cx,cy) and the device point warp p' = pi(H*[p;1]): the gyro-predicted
+ * initial flow sketched at src/track/TrackMsckfVio.cpp:344-355, R_p_c from src/propagator/TrackPropagator.h:107-153. */
 void ft_homography(const float* K4, const float* R_p_c, float* H);
 int ft_predict_flow(ft_ctx* ctx, const float* H, const float* xy, float* xy_out, int n);
 
