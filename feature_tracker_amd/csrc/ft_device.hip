@@ -741,6 +741,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.nlev = nlev;
     a.win_w = prm->win_w; a.win_h = prm->win_h;
     a.segs = (prm->win_w + seglen - 1) / seglen;
+    a.segs_inv = (65536 + a.segs - 1) / a.segs;
     a.max_level = max_level_all;
     a.max_iter = std::min(std::max(prm->max_iter, 0), 100);
     a.flags = prm->flags;

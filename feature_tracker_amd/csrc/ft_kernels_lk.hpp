@@ -47,6 +47,7 @@ struct LKArgs {
     int total;                // number of points
     int nlev;                 // levels per iters row
     int win_w, win_h, segs;
+    int segs_inv;             // ceil(65536 / segs): lane / segs == (lane * segs_inv) >> 16 for lane < 64
     int max_level;            // already clamped to the pyramids
     int max_iter;
     int flags;
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     const int lane = threadIdx.x;
     const LKJobDev* job = a.jobs + a.pt_job[pt];
     const int ww = a.win_w, wh = a.win_h;
-    const int r = lane / a.segs, s = lane - r * a.segs;
+    const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
     const int x0 = s * SEGLEN;
     const bool row_ok = r < wh;
     const int rc = row_ok ? r : wh - 1;          // lanes below the window reuse its last row (results masked)
