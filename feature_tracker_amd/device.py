@@ -402,7 +402,8 @@ class DeviceContext:
         t = ft_kernel_time()
         self._check(self.lib.ft_kernel_times(self._ctx, C.byref(t), int(reset)), "ft_kernel_times")
         return {"pyramid_ms": t.pyramid_ms, "pyramid_launches": t.pyramid_launches, "lk_ms": t.lk_ms,
-                "lk_launches": t.lk_launches, "fast_ms": t.fast_ms, "fast_launches": t.fast_launches}
+                "lk_launches": t.lk_launches, "fast_ms": t.fast_ms, "fast_launches": t.fast_launches,
+                "lk_points": t.lk_points, "lk_level_visits": t.lk_level_visits, "lk_iterations": t.lk_iterations}
 
     def queue_time_begin(self):
         self._check(self.lib.ft_queue_time_begin(self._ctx), "ft_queue_time_begin")
