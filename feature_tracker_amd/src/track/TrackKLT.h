@@ -8,8 +8,8 @@
 //  * with speculative_detect the detector runs on every new frame right after its pyramid, so that topping the
 //    previous frame up at the next call (src/track/TrackKLT.cpp:76-78) needs no extra device round trip; the
 //    per-cell lists are ranked, so truncating them to the count actually needed gives what the reference computes.
-// The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) is not part of this build yet:
-// mask_out is the LK status.
+// The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) is the option reject_outliers (a seeded
+// RANSAC of this build's own definition, off by default: then mask_out is the LK status).
 #pragma once
 #include <vector>
 
