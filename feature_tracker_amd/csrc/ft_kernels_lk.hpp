@@ -59,6 +59,12 @@ struct LKArgs {
 
 constexpr int LK_MARGIN = 5;                                     // staged margin around the target window, pixels
 constexpr int LK_RW_DWORDS = (32 + 1 + 2 * LK_MARGIN + 3 + 3) / 4;   // widest staged row: 12 dwords
+// LDS row pitch in dwords, per segment length.  Lane (row r, segment s) reads dwords pitch*r + (SEGLEN/4)*s + q of a
+// region, 32 lanes per bank group.  4-pixel segments (15x15: four lanes per row) are conflict-free at the row width
+// itself.  8-pixel segments (21x21: three lanes per row, two dwords apart) at pitch 12 touch only even banks and
+// only 8 distinct row offsets, three addresses per bank; no pitch makes 32 such lanes conflict-free (ten rows and
+// two lanes do not tile 32 banks), 19 leaves one bank group clean and the other with a single two-way conflict.
+template <int SEGLEN> struct LkPitch { static constexpr int value = SEGLEN == 4 ? 12 : (SEGLEN == 8 ? 19 : 13); };
 
 typedef short lk_v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lk_v2s v2s(uint32_t x) { return __builtin_bit_cast(lk_v2s, x); }
@@ -189,7 +195,7 @@ struct __attribute__((packed)) LkU32Unaligned { uint32_t v; };
 // Lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...; the LDS array holds 4*MAXR rows.
 // A lane issues all its loads before the first one is consumed, so a region costs one memory round trip.  The
 // caller orders the LDS writes before its reads with lds_fence().
-template <int MAXR>
+template <int MAXR, int LK_PITCH>
 __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
                                                int x_first, int x_last, int y_first, int n_rows, int lane, int a_reach_w, int a_reach_h) {
     Region R;
@@ -211,9 +217,9 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
                 const int sy = min(R.ry0 + rr + 4 * k, h - 1);
                 v[k] = *reinterpret_cast<const uint32_t*>(img + (__umul24(sy, pitch) + (uint32_t)gx));   // uniform base + 32-bit offset
             }
-            uint32_t* dst = lds + rr * LK_RW_DWORDS + c;
+            uint32_t* dst = lds + rr * LK_PITCH + c;
 #pragma unroll
-            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_RW_DWORDS] = v[k];
+            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_PITCH] = v[k];
         }
         return R;
     }
@@ -241,9 +247,9 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
                 va[k] = reinterpret_cast<const LkU32Unaligned*>(img + (ro + offA))->v;
                 vb[k] = reinterpret_cast<const LkU32Unaligned*>(img + (ro + offB))->v;
             }
-            uint32_t* dst = lds + rr * LK_RW_DWORDS + c;
+            uint32_t* dst = lds + rr * LK_PITCH + c;
 #pragma unroll
-            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_RW_DWORDS] = __builtin_amdgcn_perm(vb[k], va[k], sel);
+            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_PITCH] = __builtin_amdgcn_perm(vb[k], va[k], sel);
         }
         return R;
     }
@@ -254,7 +260,7 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
             uint32_t t = 0;
 #pragma unroll 1
             for (int b = 0; b < 4; b++) t |= (uint32_t)src[reflect101(gx + b, w)] << (8 * b);
-            lds[row * LK_RW_DWORDS + c] = t;
+            lds[row * LK_PITCH + c] = t;
         }
     }
     return R;
@@ -272,10 +278,10 @@ __device__ __forceinline__ bool region_holds(const Region& R, int inx, int iny, 
 
 // 2*NP consecutive bytes of one staged row starting at byte offset byte_off, as NP pairs of 16-bit values:
 // P[m] = (byte 2m, byte 2m+1)
-template <int NP>
+template <int NP, int LK_PITCH>
 __device__ __forceinline__ void read_row_pairs_even(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&P)[NP]) {
     constexpr int NE = (2 * NP + 3) / 4;
-    const uint32_t* p = lds + row * LK_RW_DWORDS + (byte_off >> 2);
+    const uint32_t* p = lds + row * LK_PITCH + (byte_off >> 2);
     const uint32_t sh = byte_off & 3;
     uint32_t d[NE + 1];
 #pragma unroll
@@ -289,10 +295,10 @@ __device__ __forceinline__ void read_row_pairs_even(const uint32_t* __restrict__
 }
 
 // (J[k], J[k+1]) pairs, k = 0..SEGLEN-1, of one staged row as packed 16-bit pairs for v_dot2
-template <int SEGLEN>
+template <int SEGLEN, int LK_PITCH>
 __device__ __forceinline__ void read_row_pairs(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&pairs)[SEGLEN]) {
     constexpr int NDW = SEGLEN / 4 + 1;
-    const uint32_t* p = lds + row * LK_RW_DWORDS + (byte_off >> 2);
+    const uint32_t* p = lds + row * LK_PITCH + (byte_off >> 2);
     const uint32_t sh = byte_off & 3;
     uint32_t d[NDW + 1];
 #pragma unroll
@@ -354,8 +360,9 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
     constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
-    __shared__ uint32_t jlds[4 * J_ROWS * LK_RW_DWORDS + 4];        // target region (+ slack: row reads are dword-granular)
-    __shared__ uint32_t ilds[4 * I_ROWS * LK_RW_DWORDS + 4];        // template region: window + Scharr apron
+    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
+    __shared__ uint32_t jlds[4 * J_ROWS * LK_PITCH + 4];        // target region (+ slack: row reads are dword-granular)
+    __shared__ uint32_t ilds[4 * I_ROWS * LK_PITCH + 4];        // template region: window + Scharr apron
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     const int lane = threadIdx.x;
@@ -435,11 +442,11 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         const uint8_t* imgJ = level_img(a.A, img_J, level);
         nx -= half_x; ny -= half_y;
         const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-        const Region RI = stage_region<I_ROWS>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
+        const Region RI = stage_region<I_ROWS, LK_PITCH>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
         Region R;
         R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
         if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h))
-            R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+            R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
         lds_fence();
 
         // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
@@ -455,9 +462,9 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
             const int boff = ipx + x0 - 1 - RI.rx0;
             uint32_t Ra[NP], Rb[NP], Rc[NP], Rd[NP];
-            read_row_pairs_even<NP>(ilds, rc, boff, Ra);
-            read_row_pairs_even<NP>(ilds, rc + 1, boff, Rb);
-            read_row_pairs_even<NP>(ilds, rc + 2, boff, Rc);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
             int sX[SEGLEN], sY[SEGLEN];
 #pragma unroll
             for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
@@ -467,7 +474,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
             else scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, ipx + x0 - 1, w);
             __builtin_amdgcn_sched_barrier(0);
-            read_row_pairs_even<NP>(ilds, rc + 3, boff, Rd);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 3, boff, Rd);
             if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
             else scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, ipx + x0 - 1, w);
             __builtin_amdgcn_sched_barrier(0);
@@ -512,15 +519,15 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             }
             n_iter = j + 1;
             if (!region_holds(R, inx, iny, ext_w, wh)) {
-                R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
                 lds_fence();
             }
             const BilinW jw = bilin_weights(nx - inx, ny - iny);
             const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
             uint32_t p0[SEGLEN], p1[SEGLEN];
             const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
-            read_row_pairs<SEGLEN>(jlds, row, boff, p0);
-            read_row_pairs<SEGLEN>(jlds, row + 1, boff, p1);
+            read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
+            read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int m = 0; m < SEGLEN / 2; m++) {
@@ -555,15 +562,15 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 st = 0;
             } else {
                 if (!region_holds(R, iqx, iqy, ext_w, wh)) {
-                    R = stage_region<J_ROWS>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+                    R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
                     lds_fence();
                 }
                 const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
                 const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
                 uint32_t p0[SEGLEN], p1[SEGLEN];
                 const int boff = iqx - R.rx0 + x0, row = iqy - R.ry0 + rc;
-                read_row_pairs<SEGLEN>(jlds, row, boff, p0);
-                read_row_pairs<SEGLEN>(jlds, row + 1, boff, p1);
+                read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
+                read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
                 int e = 0;
 #pragma unroll
                 for (int k = 0; k < SEGLEN; k++) {
