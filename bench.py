@@ -299,6 +299,8 @@ def main():
             "stream_groups": groups,
             "setup": {"sequence_generation_s": t_gen},
         }
+        if not args.host_frames:
+            out["kernels"]["pyramid_gradient_build"] = pyramid_gradient_build(ftdev, wl, seqs, local_rank)
         if not args.no_latency:
             out["latency"] = single_stream_latency(tracker, local_rank)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on a single-GPU run only
@@ -307,6 +309,31 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pyramid_gradient_build(ftdev, wl, seqs, device, reps=20):
+    """The pyramid + Scharr gradient image build on its own (ft_build_pyramid with gradient images: every level is
+    read once and its gradient image and the next level are written), all streams of one step per launch group.  This
+    is the HBM-bound part of the path; the tracking pipeline itself evaluates the gradients inside the LK kernel and
+    writes no gradient image."""
+    S, w, h, lv = wl["streams"], wl["w"], wl["h"], wl["opts"]["pyr_levels"]
+    with ftdev.DeviceContext(w, h, max_levels=lv + 1, n_streams=S, n_slots=1, max_points=64, max_grid_cells=25, max_per_cell=2,
+                             device=device) as ctx:
+        for s in range(S):
+            ctx.upload(s, 0, seqs[s].frames[0])
+        streams, slots = list(range(S)), [0] * S
+        ctx.build_pyramid(streams, slots, lv, wl["opts"]["win_size"], with_gradients=True)
+        ctx.sync()
+        ctx.profile(True)
+        ctx.kernel_times()
+        for _ in range(reps):
+            ctx.build_pyramid(streams, slots, lv, wl["opts"]["win_size"], with_gradients=True)
+        t = ctx.kernel_times()
+        ctx.profile(False)
+    ms = t["pyramid_ms"] / max(1, t["pyramid_launches"])
+    by = pyramid_kernel_bytes(w, h, lv, with_gradients=True, with_ingest=False) * S
+    return dict(kernel="level_kernel with gradient images (one launch per level, all streams of one step)", avg_ms=ms, launches=reps,
+                algorithmic_bytes=by, achieved_gbs=by / (ms * 1e-3) / 1e9, frac_hbm_peak=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
 
 def single_stream_latency(tracker, device, n=120):
