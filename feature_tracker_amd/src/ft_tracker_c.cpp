@@ -216,7 +216,9 @@ struct ftk_group {
                 if (stop) return;
             }
             Mail& M = mail[next & (MAIL_RING - 1)];
-            M.rc = batch->begin(M.ts.data(), M.frames.data());
+            // nothing else waiting: the caller feeds one set at a time, so keep the detector out of this set's latency
+            const bool late_detect = posted.load(std::memory_order_acquire) == next;
+            M.rc = batch->begin(M.ts.data(), M.frames.data(), late_detect);
             // lookahead: if the following set is already in the mailbox, queue its ingest, pyramids and detector now so
             // that the device stays busy while this set's results are processed
             if (M.rc == FT_OK && posted.load(std::memory_order_acquire) > next) {

@@ -185,16 +185,20 @@ void TrackKLT::mono_finish(MonoPlan& plan, const Detection& cur_det) {
         }
     }
     // keep the ranked detection of this frame for the next call
-    cache_valid = cur_det.valid;
-    if (cur_det.valid) {
-        cache_kps.assign(cur_det.kps, cur_det.kps + cur_det.n);
-        cache_cell_counts.assign(cur_det.cell_counts, cur_det.cell_counts + cur_det.cells);
-        cache_per_cell = cur_det.per_cell;
-        cache_n = cur_det.n;
-    }
+    set_cached_detection(cur_det);
     cs.slot_last = plan.slot_cur;
     cs.cols = plan.cols; cs.rows = plan.rows;
     cs.t_last = plan.timestamp;
+}
+
+void TrackKLT::set_cached_detection(const Detection& det) {
+    cache_valid = det.valid;
+    if (det.valid) {
+        cache_kps.assign(det.kps, det.kps + det.n);
+        cache_cell_counts.assign(det.cell_counts, det.cell_counts + det.cells);
+        cache_per_cell = det.per_cell;
+        cache_n = det.n;
+    }
 }
 
 void TrackKLT::mono_commit(MonoPlan& plan) {

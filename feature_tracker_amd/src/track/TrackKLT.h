@@ -90,6 +90,9 @@ public:
     // 4. ... and written to the feature database here (src/track/TrackKLT.cpp:187-198).  Nothing in the next frame's
     //    tracking depends on it, so a driver may run it while the device works on the next frame.
     void mono_commit(MonoPlan& plan);
+    // the ranked detection of the last frame, for a driver whose detector finishes after mono_finish (which then got
+    // an invalid detection)
+    void set_cached_detection(const Detection& det);
 
     // depth of the pyramid slot ring the monocular path cycles through (2 = previous + current; a driver that
     // ingests frame k+1 while frame k is still being tracked needs 3).  The backend must have that many slots.

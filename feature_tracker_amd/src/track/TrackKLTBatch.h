@@ -32,6 +32,10 @@ public:
         pool = own_pool.get();
     }
 
+    ~TrackKLTBatch() {
+        if (late_pending) (void)be->wait(det_token);   // the backend still holds pointers into det[] for that delivery
+    }
+
     static int default_host_threads(int n_streams) {
         const int hw = (int)std::thread::hardware_concurrency();
         return std::max(1, std::min(std::min(hw > 0 ? hw : 1, 8), n_streams / 4));
@@ -100,7 +104,12 @@ public:
     // first half of feed(): host preparation and every device launch of the frame set; returns without waiting.
     // A driver that owns several batches on separate device contexts overlaps one batch's device work with another
     // batch's host bookkeeping by interleaving begin() and complete() calls.
-    int begin(const double* timestamps, const FrameSource* frames) {
+    // late_detect (speculative detection only): queue the detector of the new frames AFTER their tracking launch.
+    // complete() then waits for the tracking results alone, and the ranked detections are collected at the start of
+    // the next begin(), where they are first needed (or in complete(), if a stream starts from nothing and needs
+    // them at once).  For a caller that feeds one set at a time and waits for it, this takes the detector out of
+    // the frame's latency; results are the same.
+    int begin(const double* timestamps, const FrameSource* frames, bool late_detect = false) {
         const int S = size();
         if (S == 0) return FT_OK;
         using clk = std::chrono::steady_clock;
@@ -131,14 +140,20 @@ public:
             staged = false;
             // a stale staging only wrote ring slots this set overwrites; its detector output lands in det[staged_det]
             det_cur = front_done ? staged_det : (staged_det ^ 1);
+            if (late_pending && det_cur == late_idx && (rc = resolve_late()) != FT_OK) return rc;
+        } else if (late_pending && det_cur == late_idx) {
+            det_cur ^= 1;   // det[late_idx] still receives the previous set's detector output
         }
+        const bool late = late_detect && t0.speculative() && !front_done && cells > 0;
         if (!front_done) {
             const std::function<void(int)> lap_fn = lap;
-            if ((rc = enqueue_front(timestamps, frames, cur_slots, det[det_cur], t0.speculative(), &lap_fn)) != FT_OK) return rc;
+            if ((rc = enqueue_front(timestamps, frames, cur_slots, det[det_cur], t0.speculative() && !late, &lap_fn)) != FT_OK) return rc;
         } else {
             lap(ST_INGEST);
         }
         lap(ST_PYRAMID);
+        // the previous set's late detector output: it ran while this set's frames were ingested
+        if (late_pending && (rc = resolve_late()) != FT_OK) return rc;
         // detections of the previous frames: cached (speculative) or computed now for the streams that need them
         std::vector<Detection> last_det(S);
         if (t0.speculative()) {
@@ -208,6 +223,12 @@ public:
         // the wait in complete() covers this set's detector and LK, not what stage() enqueues afterwards
         if ((rc = be->fence(&wait_token)) != FT_OK) return rc;
         lap(ST_LK_ENQUEUE);
+        if (late) {
+            if ((rc = enqueue_detect(frames, cur_slots, det[det_cur])) != FT_OK) return rc;
+            if ((rc = be->fence(&det_token)) != FT_OK) return rc;
+            late_pending = true; late_idx = det_cur; late_cells = cells; late_kmax = kmax;
+            lap(ST_DETECT);
+        }
         flush_db();   // the previous set's database writes overlap the device work queued above
         lap(ST_FINISH);
         stage_s[ST_TOTAL] += std::chrono::duration<double>(mark - t_begin).count();
@@ -235,13 +256,16 @@ public:
         lap(ST_WAIT);
         std::vector<Detection>& cur_det = cur_det_buf;
         cur_det.assign(S, Detection());
-        const int cap = cells * kmax;
-        const DetSet& D = det[det_cur];
-        for (size_t q = 0; q < D.who.size(); q++) {
-            Detection& d = cur_det[D.who[q]];
-            d.valid = true; d.per_cell = kmax; d.cells = cells;
-            d.kps = D.buf.data() + q * cap; d.n = D.n[q]; d.cell_counts = D.cells.data() + q * cells;
+        if (late_pending) {   // this set's detector is still queued behind its tracking launch
+            bool any_first = false;
+            for (int s = 0; s < S; s++) any_first |= plans[s].first;
+            if (any_first) {   // a stream that starts from nothing takes its points from the detection right now
+                if ((rc = be->wait(det_token)) != FT_OK) return rc;
+                late_pending = false;
+                lap(ST_WAIT);
+            }
         }
+        if (!late_pending) fill_detections(det[det_cur], cells, kmax, cur_det);
         pool->parallel_for(S, [&](int s) { trackers[s]->mono_finish(plans[s], cur_det[s]); });
         for (int s = 0; s < S; s++)
             if (plans[s].db_pending) { db_pending = true; break; }
@@ -329,18 +353,45 @@ private:
             if ((rc = be->build_pyramid(S, front_streams.data(), slots.data(), t0.max_level(), t0.window(), t0.window(), 0, nullptr)) != FT_OK) return rc;
         }
         D.who.clear();
-        if (detect) {
-            const int gx = t0.grid_cols(), gy = t0.grid_rows(), kmax = t0.per_cell_max();
-            const int cells = Grider_FAST::cells_for(frames[0].cols, frames[0].rows, gx, gy);
-            if (cells > 0) {
-                const int cap = cells * kmax;
-                D.who.resize(S);
-                for (int s = 0; s < S; s++) D.who[s] = s;
-                D.buf.resize((size_t)S * cap); D.n.resize(S); D.cells.resize((size_t)S * cells);
-                if ((rc = be->fast_grid_async(S, front_streams.data(), slots.data(), t0.fast_threshold(), gx, gy, kmax, D.buf.data(), cap,
-                                              D.n.data(), D.cells.data())) != FT_OK) return rc;
-            }
+        if (detect) return enqueue_detect(frames, slots, D);
+        return FT_OK;
+    }
+
+    // the ranked per-cell detector of every stream's frame in the given ring slots, one batched call
+    int enqueue_detect(const FrameSource* frames, const std::vector<int>& slots, DetSet& D) {
+        const int S = size();
+        TrackKLT& t0 = *trackers[0];
+        const int gx = t0.grid_cols(), gy = t0.grid_rows(), kmax = t0.per_cell_max();
+        const int cells = Grider_FAST::cells_for(frames[0].cols, frames[0].rows, gx, gy);
+        D.who.clear();
+        if (cells <= 0) return FT_OK;
+        const int cap = cells * kmax;
+        front_streams.resize(S);
+        D.who.resize(S);
+        for (int s = 0; s < S; s++) { front_streams[s] = s; D.who[s] = s; }
+        D.buf.resize((size_t)S * cap); D.n.resize(S); D.cells.resize((size_t)S * cells);
+        return be->fast_grid_async(S, front_streams.data(), slots.data(), t0.fast_threshold(), gx, gy, kmax, D.buf.data(), cap, D.n.data(),
+                                   D.cells.data());
+    }
+
+    static void fill_detections(const DetSet& D, int cells, int kmax, std::vector<Detection>& out) {
+        const int cap = cells * kmax;
+        for (size_t q = 0; q < D.who.size(); q++) {
+            Detection& d = out[D.who[q]];
+            d.valid = true; d.per_cell = kmax; d.cells = cells;
+            d.kps = D.buf.data() + q * cap; d.n = D.n[q]; d.cell_counts = D.cells.data() + q * cells;
         }
+    }
+
+    // collect a late detector output and hand it to the trackers as the cached detection of their last frame
+    int resolve_late() {
+        const int rc = be->wait(det_token);
+        late_pending = false;
+        if (rc != FT_OK) return rc;
+        const int S = size();
+        late_det_buf.assign(S, Detection());
+        fill_detections(det[late_idx], late_cells, late_kmax, late_det_buf);
+        for (int s = 0; s < S; s++) trackers[s]->set_cached_detection(late_det_buf[s]);
         return FT_OK;
     }
 
@@ -353,7 +404,10 @@ private:
     std::vector<double> staged_ts;
     std::vector<FrameSource> staged_frames;
     std::vector<int> staged_slots, front_streams, stage_rc;
-    uint64_t wait_token = 0;
+    uint64_t wait_token = 0, det_token = 0;
+    bool late_pending = false;
+    int late_idx = 0, late_cells = 0, late_kmax = 0;
+    std::vector<Detection> late_det_buf;
     std::vector<std::unique_ptr<TrackKLT>> trackers;
     std::vector<TrackKLT::MonoPlan> plans, db_plans;
     std::vector<char> starts_fresh;
