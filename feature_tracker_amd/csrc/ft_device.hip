@@ -708,8 +708,12 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     }
     if (N == 0) return FT_OK;
 
-    // one transfer for the whole block (jobs .. end of next_xy in use)
-    {
+    // Large batches: one transfer for the whole block (jobs .. end of next_xy in use), so that the tracking waves read
+    // their inputs from device memory.  Small batches (a single stream's worth of points) read the pinned block in
+    // place: the extra dependent launch would cost more than the few reads over the bus.
+    const bool direct_in = N <= 1024 && !stereo && !reject;
+    const uint8_t* ib = direct_in ? c->lk_in_host_dev : c->lk_in_dev;
+    if (!direct_in) {
         const int n16 = (int)((off_next + 8 * N + 15) / 16);
         hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->q, reinterpret_cast<const uint4*>(c->lk_in_host_dev),
                            reinterpret_cast<uint4*>(c->lk_in_dev), n16);
@@ -717,10 +721,10 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     LKArgs a;
     a.A = c->arena;
-    a.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
-    a.pt_job = reinterpret_cast<const uint16_t*>(c->lk_in_dev + off_ptjob);
-    a.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);
-    a.guess_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_next);
+    a.jobs = reinterpret_cast<const LKJobDev*>(ib);
+    a.pt_job = reinterpret_cast<const uint16_t*>(ib + off_ptjob);
+    a.prev_xy = reinterpret_cast<const float*>(ib + off_prev);
+    a.guess_xy = reinterpret_cast<const float*>(ib + off_next);
     // Without a backward pass (which reads the forward results on the device) and without iteration counters, lane 0
     // of every wave writes its 13 result bytes straight into the pinned host block: no copy command to enqueue.
     const bool direct_out = !fb && !want_iters && !reject && !stereo;
