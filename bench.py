@@ -203,8 +203,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # warm-up in the same feeding mode as the timed steps (pipelined), completed before the clock starts
     for i in range(W + 1):
-        b.feed_device(stamps[i], ptrs[i], w, h, w)
+        if args.host_frames:
+            b.feed_host(stamps[i], [q.frames[i] for q in seqs], pipelined=True)
+        else:
+            b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
+    b.flush()
     barrier()
     b.stage_times(reset=True)
     t0 = time.perf_counter()
@@ -348,8 +353,23 @@ def single_stream_latency(tracker, device, n=120):
         b.feed_host([q.timestamps[i]], [q.frames[i]])
         lat.append(time.perf_counter() - t0)
     lat = np.array(lat[10:]) * 1e3
-    return {"workload": "cfg2: " + wl["desc"] + ", frame uploaded from host memory", "p50_ms": float(np.percentile(lat, 50)),
-            "p95_ms": float(np.percentile(lat, 95)), "frames": n}
+    out = {"workload": "cfg2: " + wl["desc"] + ", frame uploaded from host memory", "p50_ms": float(np.percentile(lat, 50)),
+           "p95_ms": float(np.percentile(lat, 95)), "frames": n}
+    # the same stream with its frames in page-locked host memory: the level-0 pass reads them in place over the bus,
+    # so the copy into the library's staging buffer drops out
+    import torch
+    del b
+    pinned = torch.from_numpy(q.frames).pin_memory()
+    b = setup_tracker(tracker, wl, [q], device=device)
+    lat = []
+    for i in range(n + 10):
+        t0 = time.perf_counter()
+        b.feed_device([q.timestamps[i]], [pinned[i].data_ptr()], wl["w"], wl["h"], wl["w"])
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat[10:]) * 1e3
+    out["pinned_frames"] = {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
+                            "note": "frames in page-locked host memory, read in place by the level-0 pass"}
+    return out
 
 
 if __name__ == "__main__":
