@@ -138,3 +138,31 @@ def test_pipelined_groups_with_lookahead_equal_plain_feed():
         assert n_a == n_b and tr_a.keys() == tr_b.keys()
         for k in tr_a:
             assert np.array_equal(tr_a[k][0], tr_b[k][0]) and np.array_equal(tr_a[k][1], tr_b[k][1])
+
+
+def test_late_detector_with_streams_that_lose_tracking():
+    """One-set-at-a-time feeds queue the detector after the tracking launch and collect it at the next feed; a stream
+    that lost everything (blank frames) needs the detection of its new frame at once.  Must equal the CPU checker fed
+    the same way and the pipelined feed (detector before tracking), frame by frame."""
+    O.lib()
+    n_frames = 12
+    seqs = [synth.Sequence(376, 240, n_frames, stream_id=60 + s) for s in range(3)]
+    seqs[0].frames[4:6] = 128          # stream 0 goes blank for two frames, then the scene is back
+    seqs[2].frames[7] = 10             # stream 2 for one
+    opts = dict(win_size=15, pyr_levels=2, num_pts=80, use_gyro_seed=1)
+    gpu = _feed_all(tracker.BatchTracker(3, 376, 240, **opts), seqs, n_frames)
+    cpu = _feed_all(tracker.BatchTracker(3, 376, 240, lib_path=ORC, **opts), seqs, n_frames)
+    _same_run(gpu, cpu)
+    assert len(gpu[5][2][0][0]) == 0 and len(gpu[7][2][0][0]) > 40      # lost, then found again
+    # pipelined, two groups: the detector runs before the tracking launch there
+    b = tracker.BatchTracker(3, 376, 240, n_groups=2, **opts)
+    for s, q in enumerate(seqs):
+        b.set_calibration(s, q.calib8, q.T_cam_imu)
+        for t, g, a in zip(q.imu_t, q.gyro, q.accel):
+            b.feed_imu(s, t, a, g)
+    for i in range(n_frames):
+        b.feed_host([q.timestamps[i] for q in seqs], [q.frames[i] for q in seqs], pipelined=True)
+    b.flush()
+    for s in range(3):
+        xy, ids = b.points(s)
+        assert np.array_equal(ids, gpu[-1][2][s][1]) and np.array_equal(xy, gpu[-1][2][s][0])
