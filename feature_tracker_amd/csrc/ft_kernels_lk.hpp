@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
             if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
                 st = 0;
-            } else {
+            } else if (!(a.flags & FT_LK_NO_ERROR)) {
                 if (!region_holds(R, iqx, iqy, ext_w, wh)) {
                     R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
                     lds_fence();

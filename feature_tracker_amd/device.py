@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libft_device.so")
 
 FT_LK_USE_INITIAL_FLOW = 4
 FT_LK_GET_MIN_EIGENVALS = 8
+FT_LK_NO_ERROR = 1024
 FT_LK_FORWARD_BACKWARD = 256
 FT_LK_REJECT_OUTLIERS = 512
 FT_MAX_LEVELS = 8

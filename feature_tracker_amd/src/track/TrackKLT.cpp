@@ -15,7 +15,9 @@ ft_lk_params TrackKLT::lk_params() const {
     p.max_iter = lk_max_iter;                // TermCriteria(COUNT + EPS, 15, 0.01), TrackKLT.cpp:305,:401
     p.eps = lk_eps;
     p.min_eig = lk_min_eig;
-    p.flags = FT_LK_USE_INITIAL_FLOW | (forward_backward ? FT_LK_FORWARD_BACKWARD : 0) | (reject_outliers ? FT_LK_REJECT_OUTLIERS : 0);
+    // the residual is not computed: perform_matching never looks at it (TrackKLT.cpp:399-402)
+    p.flags = FT_LK_USE_INITIAL_FLOW | FT_LK_NO_ERROR | (forward_backward ? FT_LK_FORWARD_BACKWARD : 0) |
+              (reject_outliers ? FT_LK_REJECT_OUTLIERS : 0);
     p.fb_thresh = fb_thresh;
     p.ransac_hypotheses = ransac_hypotheses;     // TrackKLT.cpp:405-424
     p.ransac_seed = frames_fed;

@@ -50,6 +50,10 @@ extern "C" {
  * sampling is this library's own seeded scheme, because OpenCV's random sequence cannot be reproduced without it.
  * Jobs need calib_prev / calib_next. */
 #define FT_LK_REJECT_OUTLIERS 512
+/* Do not compute the residual (err stays 0).  TrackKLT::perform_matching never reads the `error` vector it gets from
+ * cv::calcOpticalFlowPyrLK (src/track/TrackKLT.cpp:399-402), so the tracker layer sets this; status is unaffected
+ * (the bounds test of the final position, which can still clear it, is kept). */
+#define FT_LK_NO_ERROR 1024
 
 typedef struct ft_ctx ft_ctx;
 

@@ -320,6 +320,7 @@ void lk_point_level(const LKCtx& c, int level, int i, std::vector<int16_t>& Ibuf
             c.status[i] = 0;
             return;
         }
+        if (c.flags & FTO_LK_NO_ERROR) return;   // the caller does not read the residual (it stays 0)
         float aa = qx - iqx, bb = qy - iqy;
         iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
         iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));

@@ -24,6 +24,7 @@ extern "C" {
 /* flag values follow OpenCV's OPTFLOW_* enum so the call sites read the same */
 #define FTO_LK_USE_INITIAL_FLOW 4
 #define FTO_LK_GET_MIN_EIGENVALS 8
+#define FTO_LK_NO_ERROR 1024        /* leave err at 0 (the bounds test of the final position still applies to status) */
 #define FTO_LK_FORWARD_BACKWARD 256 /* build-defined: see fto_lk_track */
 #define FTO_LK_REJECT_OUTLIERS 512  /* build-defined: see fto_reject_outliers (applied by the tracker backend) */
 

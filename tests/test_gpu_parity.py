@@ -163,6 +163,14 @@ def test_lk_initial_guess_no_initial_flow_and_min_eig(dev):
             out = ctx.lk_track([job], dev.LKParams(win=15, max_level=3, flags=flags))[0]
             _compare_lk(out, ref)
             assert np.array_equal(out[2], ref[2])   # err (residual or min eigenvalue) identical
+        # without the residual: same positions and status flags as with it, err left at 0
+        with_err = ctx.lk_track([job], dev.LKParams(win=15, max_level=3))[0]
+        flags = dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_NO_ERROR
+        ref = O.lk_track(rp, rn, pts, guess=guess, win=15, max_level=3, flags=flags)
+        out = ctx.lk_track([job], dev.LKParams(win=15, max_level=3, flags=flags))[0]
+        _compare_lk(out, ref)
+        assert np.array_equal(out[0], with_err[0]) and np.array_equal(out[1], with_err[1])
+        assert not out[2].any() and not ref[2].any() and with_err[2].any()
         # tight termination settings
         ref = O.lk_track(rp, rn, pts, guess=guess, win=15, max_level=3, max_iter=3, eps=0.1, min_eig=5e-3)
         out = ctx.lk_track([job], dev.LKParams(win=15, max_level=3, max_iter=3, eps=0.1, min_eig=5e-3))[0]
