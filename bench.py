@@ -49,10 +49,10 @@ MEASURED_TRAFFIC = {
 
 
 # Vector-ALU instructions per wavefront-lane-group ("wave instructions") per unit of work, from a rocprofv3 SQ_INSTS_VALU
-# / SQ_WAVES pass over this workload (profiles/r1_h_pmc_insts.txt).  These kernels are bound by vector-instruction issue,
+# / SQ_WAVES pass over this workload (profiles/r1_j_pmc_insts.txt; level_kernel figures from r1_h_pmc_insts.txt, where they are not mixed with the gradient leg).  These kernels are bound by vector-instruction issue,
 # not by HBM: one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
 MEASURED_VALU = {
-    ("cfg4", "lk_track"): (4160.0, "point"),                                   # one wave per point
+    ("cfg4", "lk_track"): (4027.8, "point"),                                   # one wave per point
     ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
     ("cfg4", "fast_grid"): ((610.0 * 26624 + 252.2 * 1600) / 64.0, "frame"),
 }
