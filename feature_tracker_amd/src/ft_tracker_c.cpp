@@ -411,9 +411,10 @@ int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, 
                              int n_groups, int host_threads) {
     if (!out || !valid_options(o) || n_streams < 1 || n_streams > FT_MAX_BATCH || max_width < 1 || max_height < 1) return FT_E_INVALID;
     *out = nullptr;
-    // two groups overlap one group's host bookkeeping with the other's device work; more submitting threads per
-    // device only contend inside the HIP runtime (measured: 2 groups beat 3, 4 and 8 on 64 streams)
-    if (n_groups <= 0) n_groups = n_streams >= 8 ? 2 : 1;
+    // groups overlap one group's host bookkeeping with the others' device work.  Measured on 64 streams: 3 groups
+    // 63.5 M features/s, 2 groups 61.2 M, 4 groups 44.7 M (more submitting threads contend inside the HIP runtime, and
+    // batches below about 20 streams run the kernels less efficiently)
+    if (n_groups <= 0) n_groups = n_streams >= 48 ? 3 : (n_streams >= 8 ? 2 : 1);
     n_groups = std::min(n_groups, n_streams);
     // host threads: one driver per group plus helpers for the per-stream bookkeeping inside each group
     if (host_threads <= 0) {
