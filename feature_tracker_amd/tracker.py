@@ -197,15 +197,21 @@ class BatchTracker(_Base):
     def feed_device(self, timestamps, dev_ptrs, w, h, stride, pipelined=False):
         """dev_ptrs: n device addresses of frames resident in HBM.  pipelined=True leaves the last group's frame in
         flight (finish with flush()); the returned counts are those of the frames completed by the call."""
+        if isinstance(dev_ptrs, C.Array):     # a prepared (c_void_p * n) array: no per-frame marshalling
+            return self._feed(timestamps, 1, w, h, stride, pipelined, ptrs=dev_ptrs)
         for i, p in enumerate(dev_ptrs):
             self._ptrs[i] = int(p)
         return self._feed(timestamps, 1, w, h, stride, pipelined)
 
-    def _feed(self, timestamps, on_device, w, h, stride, pipelined=False):
-        self._ts[:] = timestamps
+    def _feed(self, timestamps, on_device, w, h, stride, pipelined=False, ptrs=None):
+        if isinstance(timestamps, np.ndarray) and timestamps.dtype == np.float64 and timestamps.flags.c_contiguous:
+            ts = timestamps                   # a prepared array: used as it is
+        else:
+            self._ts[:] = timestamps
+            ts = self._ts
         tracked, attempted = C.c_longlong(), C.c_longlong()
         fn = self.lib.ftk_batch_feed_pipelined if pipelined else self.lib.ftk_batch_feed
-        self._check(fn(self._h, _dp(self._ts), self._ptrs, on_device, w, h, stride, C.byref(tracked), C.byref(attempted)), "ftk_batch_feed")
+        self._check(fn(self._h, _dp(ts), self._ptrs if ptrs is None else ptrs, on_device, w, h, stride, C.byref(tracked), C.byref(attempted)), "ftk_batch_feed")
         return tracked.value, attempted.value
 
     def flush(self):
