@@ -16,6 +16,7 @@
 //
 // The backend comes from ftk_make_backend(): the product binary links the gfx950 device library and fails without
 // a GPU; the test suite links the same file against its CPU checker.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
