@@ -75,6 +75,8 @@ bool TrackKLT::gyro_homography(size_t cam_id, double t_last, double t_cur, float
 // ---------------------------------------------------------------------------------------------------------------
 
 void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, MonoPlan& plan) {
+    for (StereoDet& D : stereo_cache)   // a stereo-path detection of this camera's stream does not survive monocular feeds
+        if (D.stream == stream0 + (int)cam_id) D.valid = false;
     CamState& cs = cams[cam_id];
     // reset the plan but keep the capacity of its arrays
     plan.first = plan.run_lk = plan.reset = plan.use_H = plan.db_pending = false;
@@ -323,6 +325,38 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
     }
 }
 
+void TrackKLT::promote_stereo_detection() {
+    if (!spec_pending) return;
+    spec_pending = false;
+    const bool ok = be->sync() == FT_OK;   // delivers the detector output if an earlier wait has not done so already
+    for (int i = 0; i < 2; i++) {
+        StereoDet& D = stereo_cache[i];
+        D.valid = ok;
+        if (!ok) continue;
+        D.stream = spec_stream[i]; D.slot = spec_slot[i]; D.per_cell = spec_per_cell; D.cells = spec_ncells; D.n = spec_n[i];
+        D.kps.assign(spec_kps.begin() + (size_t)i * spec_cap, spec_kps.begin() + (size_t)i * spec_cap + spec_n[i]);
+        D.cell_counts.assign(spec_cells.begin() + (size_t)i * spec_ncells, spec_cells.begin() + (size_t)(i + 1) * spec_ncells);
+    }
+}
+
+bool TrackKLT::grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out) {
+    for (const StereoDet& D : stereo_cache) {
+        if (!D.valid || D.stream != img.stream || D.slot != img.slot) continue;
+        // first num_needed/(grid_x*grid_y)+1 entries of every cell of the ranked lists, cells in index order: what
+        // Grider_FAST::perform_griding returns for this count (Grider_FAST.h:88,:118-130)
+        const int k = num_needed / (grid_x * grid_y) + 1;
+        if (k > D.per_cell) break;
+        int off = 0;
+        for (int c = 0; c < D.cells; c++) {
+            const int kept = std::min(D.cell_counts[c], D.per_cell);
+            for (int r = 0; r < kept && r < k && off + r < D.n; r++) out.push_back(Grider_FAST::to_keypoint(D.kps[off + r]));
+            off += kept;
+        }
+        return true;
+    }
+    return Grider_FAST::perform_griding(img, out, num_needed, grid_x, grid_y, threshold, true) == FT_OK;
+}
+
 void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
                                         std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
                                         size_t cam_id_left, size_t cam_id_right) {
@@ -334,7 +368,7 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
     const int num_featsneeded_0 = num_features - (int)pts0.size();
     if (num_featsneeded_0 > 1) {
         std::vector<KeyPoint> pts0_ext;
-        Grider_FAST::perform_griding(img0, pts0_ext, num_featsneeded_0, grid_x, grid_y, threshold, true);
+        grid_points(img0, num_featsneeded_0, pts0_ext);
         std::vector<KeyPoint> kpts0_new;
         for (const KeyPoint& kpt : pts0_ext) {
             if (grid0.taken(kpt.pt)) continue;
@@ -385,7 +419,7 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
     const int num_featsneeded_1 = num_features - (int)pts1.size();
     if (num_featsneeded_1 > 1) {
         std::vector<KeyPoint> pts1_ext;
-        Grider_FAST::perform_griding(img1, pts1_ext, num_featsneeded_1, grid_x, grid_y, threshold, true);
+        grid_points(img1, num_featsneeded_1, pts1_ext);
         for (const KeyPoint& kpt : pts1_ext) {
             if (grid1.taken(kpt.pt)) continue;
             pts1.push_back(kpt);
@@ -406,20 +440,39 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     const int cur_l = cl.slot_last == 0 ? 1 : 0, cur_r = cr.slot_last == 0 ? 1 : 0;
 
     // ingest both frames and build both pyramids (with gradients) in one batched launch per level (TrackKLT.cpp:45-58)
-    if (be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
-    if (be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
     const int streams[2] = {sl, sr}, slots[2] = {cur_l, cur_r};
-    if (img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows) {
-        if (be->build_pyramid(2, streams, slots, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
+    if (img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows && sl != sr) {
+        // both frames through the pinned staging buffers; level 0 and the pyramids come out of one pass over them
+        if (be->stage_frame(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
+        if (be->stage_frame(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
+        if (be->set_frames_staged_pyramid(2, streams, slots, img_leftin.cols, img_leftin.rows, pyr_levels, win_size, win_size, nullptr) != FT_OK) return;
     } else {
+        if (be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
+        if (be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
         if (be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
         if (be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
     }
     const DeviceImage cur_left{be, sl, cur_l, img_leftin.cols, img_leftin.rows};
     const DeviceImage cur_right{be, sr, cur_r, img_rightin.cols, img_rightin.rows};
+    // speculative detection: the ranked detector of both new frames is queued now and runs while the host works; its
+    // output is what topping this pair up at the next call needs (the reference detects then, TrackKLT.cpp:76-78)
+    {
+        const int cells = Grider_FAST::cells_for(img_leftin.cols, img_leftin.rows, grid_x, grid_y);
+        if (speculative_detect && cells > 0 && sl != sr && img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows) {
+            spec_per_cell = per_cell_max(); spec_ncells = cells; spec_cap = cells * spec_per_cell;
+            spec_kps.resize((size_t)2 * spec_cap); spec_n.assign(2, 0); spec_cells.assign((size_t)2 * cells, 0);
+            spec_stream[0] = sl; spec_stream[1] = sr; spec_slot[0] = cur_l; spec_slot[1] = cur_r;
+            spec_pending = be->fast_grid_async(2, streams, slots, threshold, grid_x, grid_y, spec_per_cell, spec_kps.data(), spec_cap,
+                                               spec_n.data(), spec_cells.data()) == FT_OK;
+        }
+        // the slots just overwritten no longer hold the images their cached detections were made from
+        for (StereoDet& D : stereo_cache)
+            if ((D.stream == sl && D.slot == cur_l) || (D.stream == sr && D.slot == cur_r)) D.valid = false;
+    }
     auto roll = [&]() {
         cl.slot_last = cur_l; cl.cols = img_leftin.cols; cl.rows = img_leftin.rows; cl.t_last = timestamp;
         cr.slot_last = cur_r; cr.cols = img_rightin.cols; cr.rows = img_rightin.rows; cr.t_last = timestamp;
+        promote_stereo_detection();
     };
     auto& ptsL = pts_last[cam_id_left];
     auto& ptsR = pts_last[cam_id_right];
@@ -428,6 +481,7 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
 
     // first call, or tracking was lost: just extract (TrackKLT.cpp:63-72)
     if (ptsL.empty() || ptsR.empty() || cl.slot_last < 0 || cr.slot_last < 0) {
+        promote_stereo_detection();   // this pair's own detection is needed at once
         perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right);
         roll();
         return;

@@ -5,9 +5,10 @@
 //  * the two pyramids of a stereo pair, and the two temporal LK calls, are one batched launch each instead of
 //    two host threads (src/track/TrackKLT.cpp:51-58, :91-98);
 //  * the id merge uses a hash map instead of the O(N^2) search (src/track/TrackKLT.cpp:136-166);
-//  * with speculative_detect the detector runs on every new frame right after its pyramid, so that topping the
-//    previous frame up at the next call (src/track/TrackKLT.cpp:76-78) needs no extra device round trip; the
-//    per-cell lists are ranked, so truncating them to the count actually needed gives what the reference computes.
+//  * with speculative_detect the detector runs on every new frame (both frames of a stereo pair) right after its
+//    pyramid, so that topping the previous frame up at the next call (src/track/TrackKLT.cpp:76-78) needs no extra
+//    device round trip; the per-cell lists are ranked, so truncating them to the count actually needed gives what
+//    the reference computes.
 // The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) is the option reject_outliers (a seeded
 // RANSAC of this build's own definition, off by default: then mask_out is the LK status).
 #pragma once
@@ -216,6 +217,23 @@ protected:
     int cache_per_cell = 0;
     int cache_n = 0;
     bool cache_valid = false;
+
+    // stereo path, speculative detection: the ranked detections of the newest left / right frames, queued right after
+    // their pyramids and used when that pair is topped up at the next call (no detector round trip then)
+    struct StereoDet {
+        bool valid = false;
+        int stream = -1, slot = -1, per_cell = 0, cells = 0, n = 0;
+        std::vector<ft_keypoint> kps;
+        std::vector<int> cell_counts;
+    };
+    StereoDet stereo_cache[2];            // promoted results: [0] left, [1] right
+    std::vector<ft_keypoint> spec_kps;    // in flight: both images of one batched call
+    std::vector<int> spec_n, spec_cells;
+    bool spec_pending = false;
+    int spec_per_cell = 0, spec_ncells = 0, spec_cap = 0, spec_stream[2] = {-1, -1}, spec_slot[2] = {-1, -1};
+    void promote_stereo_detection();
+    // Grider_FAST::perform_griding(img, ..., num_needed, ...) from the cached detection of that image, or by a call
+    bool grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out);
 
     // scratch for feed_monocular's own one-stream batch
     std::vector<ft_keypoint> det_buf;

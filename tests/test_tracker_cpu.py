@@ -261,3 +261,21 @@ def test_batch_threads_cpp_under_thread_sanitizer(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     assert "checks passed" in res.stdout
     assert "ThreadSanitizer: data race" not in res.stderr and "ThreadSanitizer: " not in res.stderr, res.stderr[:4000]
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(use_gyro_seed=1, stereo_extrinsic_seed=1)])
+def test_stereo_speculative_detection_equals_detection_on_demand(seq, opts):
+    """feed_stereo queues the ranked detector of both new frames right after their pyramids and tops the pair up from
+    those lists at the next call; the reference detects at that next call (src/track/TrackKLT.cpp:76-78, :275, :350).
+    Same points, same ids, frame by frame - also across a loss of tracking (blank pair)."""
+    frames = seq.frames.copy()
+    frames[4] = 90
+    blanked = type("S", (), dict(w=seq.w, h=seq.h, frames=frames, timestamps=seq.timestamps, calib8=seq.calib8, T_cam_imu=seq.T_cam_imu,
+                                 imu_t=seq.imu_t, gyro=seq.gyro, accel=seq.accel))
+    right_of = lambda f: np.roll(f, -5, axis=1)
+    a = _stereo_run(blanked, right_of, ORC, n_frames=9, speculative_detect=1, **opts)
+    b = _stereo_run(blanked, right_of, ORC, n_frames=9, speculative_detect=0, **opts)
+    for fa, fb in zip(a, b):
+        for xa, xb in zip(fa, fb):
+            assert np.array_equal(xa, xb)
+    assert len(a[4][0]) < len(a[3][0]) and len(a[-1][0]) > 80 and len(set(a[-1][1].tolist()) & set(a[-1][3].tolist())) > 40
