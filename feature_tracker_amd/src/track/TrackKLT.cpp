@@ -281,7 +281,7 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
 // stereo path
 // ---------------------------------------------------------------------------------------------------------------
 
-void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
+void TrackKLT::perform_matching(std::vector<MatchJob>& jobs, const std::function<void()>& after_launch) {
     const ft_lk_params prm = lk_params();
     struct Buf { std::vector<float> p0, p1, err; std::vector<uint8_t> st; double c0[8], c1[8]; };
     std::vector<Buf> bufs(jobs.size());
@@ -313,7 +313,12 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs) {
         lk_owner.push_back(j);
     }
     if (lk.empty()) return;
-    if (be->lk_track_async((int)lk.size(), lk.data(), &prm) != FT_OK || be->sync() != FT_OK) return;
+    if (be->lk_track_async((int)lk.size(), lk.data(), &prm) != FT_OK) return;
+    // wait for the tracking results only: what the caller queues behind them keeps running after the wait
+    uint64_t token = 0;
+    const bool fenced = be->fence(&token) == FT_OK;
+    if (after_launch) after_launch();
+    if ((fenced ? be->wait(token) : be->sync()) != FT_OK) return;
     for (size_t q = 0; q < lk.size(); q++) {
         MatchJob& M = jobs[lk_owner[q]];
         Buf& B = bufs[lk_owner[q]];
@@ -333,7 +338,7 @@ void TrackKLT::promote_stereo_detection() {
         StereoDet& D = stereo_cache[i];
         D.valid = ok;
         if (!ok) continue;
-        D.stream = spec_stream[i]; D.slot = spec_slot[i]; D.per_cell = spec_per_cell; D.cells = spec_ncells; D.n = spec_n[i];
+        D.stream = spec_stream[i]; D.slot = spec_slot[i]; D.cols = spec_cols; D.rows = spec_rows; D.per_cell = spec_per_cell; D.cells = spec_ncells; D.n = spec_n[i];
         D.kps.assign(spec_kps.begin() + (size_t)i * spec_cap, spec_kps.begin() + (size_t)i * spec_cap + spec_n[i]);
         D.cell_counts.assign(spec_cells.begin() + (size_t)i * spec_ncells, spec_cells.begin() + (size_t)(i + 1) * spec_ncells);
     }
@@ -341,7 +346,7 @@ void TrackKLT::promote_stereo_detection() {
 
 bool TrackKLT::grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out) {
     for (const StereoDet& D : stereo_cache) {
-        if (!D.valid || D.stream != img.stream || D.slot != img.slot) continue;
+        if (!D.valid || D.stream != img.stream || D.slot != img.slot || D.cols != img.cols || D.rows != img.rows) continue;
         // first num_needed/(grid_x*grid_y)+1 entries of every cell of the ranked lists, cells in index order: what
         // Grider_FAST::perform_griding returns for this count (Grider_FAST.h:88,:118-130)
         const int k = num_needed / (grid_x * grid_y) + 1;
@@ -445,8 +450,10 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
         // both frames through the pinned staging buffers; level 0 and the pyramids come out of one pass over them
         if (be->stage_frame(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
         if (be->stage_frame(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
+        promote_stereo_detection();   // the previous pair's detector ran while the frames were copied
         if (be->set_frames_staged_pyramid(2, streams, slots, img_leftin.cols, img_leftin.rows, pyr_levels, win_size, win_size, nullptr) != FT_OK) return;
     } else {
+        promote_stereo_detection();
         if (be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
         if (be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
         if (be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
@@ -454,25 +461,25 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     }
     const DeviceImage cur_left{be, sl, cur_l, img_leftin.cols, img_leftin.rows};
     const DeviceImage cur_right{be, sr, cur_r, img_rightin.cols, img_rightin.rows};
-    // speculative detection: the ranked detector of both new frames is queued now and runs while the host works; its
-    // output is what topping this pair up at the next call needs (the reference detects then, TrackKLT.cpp:76-78)
-    {
-        const int cells = Grider_FAST::cells_for(img_leftin.cols, img_leftin.rows, grid_x, grid_y);
-        if (speculative_detect && cells > 0 && sl != sr && img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows) {
-            spec_per_cell = per_cell_max(); spec_ncells = cells; spec_cap = cells * spec_per_cell;
-            spec_kps.resize((size_t)2 * spec_cap); spec_n.assign(2, 0); spec_cells.assign((size_t)2 * cells, 0);
-            spec_stream[0] = sl; spec_stream[1] = sr; spec_slot[0] = cur_l; spec_slot[1] = cur_r;
-            spec_pending = be->fast_grid_async(2, streams, slots, threshold, grid_x, grid_y, spec_per_cell, spec_kps.data(), spec_cap,
-                                               spec_n.data(), spec_cells.data()) == FT_OK;
-        }
-        // the slots just overwritten no longer hold the images their cached detections were made from
-        for (StereoDet& D : stereo_cache)
-            if ((D.stream == sl && D.slot == cur_l) || (D.stream == sr && D.slot == cur_r)) D.valid = false;
-    }
+    // speculative detection: the ranked detector of both new frames, whose output is what topping this pair up at the
+    // next call needs (the reference detects then, TrackKLT.cpp:76-78).  It is queued behind this call's last tracking
+    // launch and collected at the next call, so it adds nothing to this call's latency.
+    const int spec_cells_now = Grider_FAST::cells_for(img_leftin.cols, img_leftin.rows, grid_x, grid_y);
+    const bool can_spec = speculative_detect && spec_cells_now > 0 && sl != sr && img_leftin.cols == img_rightin.cols &&
+                          img_leftin.rows == img_rightin.rows;
+    auto enqueue_spec = [&]() {
+        if (!can_spec || spec_pending) return;
+        spec_per_cell = per_cell_max(); spec_ncells = spec_cells_now; spec_cap = spec_cells_now * spec_per_cell;
+        spec_kps.resize((size_t)2 * spec_cap); spec_n.assign(2, 0); spec_cells.assign((size_t)2 * spec_cells_now, 0);
+        spec_stream[0] = sl; spec_stream[1] = sr; spec_slot[0] = cur_l; spec_slot[1] = cur_r;
+        spec_cols = img_leftin.cols; spec_rows = img_leftin.rows;
+        spec_pending = be->fast_grid_async(2, streams, slots, threshold, grid_x, grid_y, spec_per_cell, spec_kps.data(), spec_cap,
+                                           spec_n.data(), spec_cells.data()) == FT_OK;
+    };
     auto roll = [&]() {
         cl.slot_last = cur_l; cl.cols = img_leftin.cols; cl.rows = img_leftin.rows; cl.t_last = timestamp;
         cr.slot_last = cur_r; cr.cols = img_rightin.cols; cr.rows = img_rightin.rows; cr.t_last = timestamp;
-        promote_stereo_detection();
+        enqueue_spec();   // (already queued behind the tracking launch on the usual path)
     };
     auto& ptsL = pts_last[cam_id_left];
     auto& ptsR = pts_last[cam_id_right];
@@ -481,6 +488,7 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
 
     // first call, or tracking was lost: just extract (TrackKLT.cpp:63-72)
     if (ptsL.empty() || ptsR.empty() || cl.slot_last < 0 || cr.slot_last < 0) {
+        enqueue_spec();
         promote_stereo_detection();   // this pair's own detection is needed at once
         perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right);
         roll();
@@ -511,7 +519,7 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     std::vector<MatchJob> jobs(2);
     jobs[0] = MatchJob{last_left, cur_left, &ptsL, &pts_left_new, cam_id_left, cam_id_left, &mask_ll, seeded ? Hl : nullptr};
     jobs[1] = MatchJob{last_right, cur_right, &ptsR, &pts_right_new, cam_id_right, cam_id_right, &mask_rr, seeded ? Hr : nullptr};
-    perform_matching(jobs);
+    perform_matching(jobs, enqueue_spec);
 
     // not enough points: reset and re-detect next time (TrackKLT.cpp:118-129)
     if (mask_ll.empty() || mask_rr.empty()) {

@@ -12,6 +12,7 @@
 // The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) is the option reject_outliers (a seeded
 // RANSAC of this build's own definition, off by default: then mask_out is the LK status).
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "../FeatureTrackerOptions.h"
@@ -138,7 +139,8 @@ protected:
         std::vector<uint8_t>* mask_out;
         const float* H;
     };
-    void perform_matching(std::vector<MatchJob>& jobs);
+    // after_launch (optional) runs between the tracking launch and the wait for its results
+    void perform_matching(std::vector<MatchJob>& jobs, const std::function<void()>& after_launch = nullptr);
 
     // occupancy grid of (rows/min_px_dist+2) x (cols/min_px_dist+2) cells, first come wins (TrackKLT.cpp:230-263)
     struct Occupancy {
@@ -222,7 +224,7 @@ protected:
     // their pyramids and used when that pair is topped up at the next call (no detector round trip then)
     struct StereoDet {
         bool valid = false;
-        int stream = -1, slot = -1, per_cell = 0, cells = 0, n = 0;
+        int stream = -1, slot = -1, cols = 0, rows = 0, per_cell = 0, cells = 0, n = 0;
         std::vector<ft_keypoint> kps;
         std::vector<int> cell_counts;
     };
@@ -230,7 +232,7 @@ protected:
     std::vector<ft_keypoint> spec_kps;    // in flight: both images of one batched call
     std::vector<int> spec_n, spec_cells;
     bool spec_pending = false;
-    int spec_per_cell = 0, spec_ncells = 0, spec_cap = 0, spec_stream[2] = {-1, -1}, spec_slot[2] = {-1, -1};
+    int spec_per_cell = 0, spec_ncells = 0, spec_cap = 0, spec_cols = 0, spec_rows = 0, spec_stream[2] = {-1, -1}, spec_slot[2] = {-1, -1};
     void promote_stereo_detection();
     // Grider_FAST::perform_griding(img, ..., num_needed, ...) from the cached detection of that image, or by a call
     bool grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out);
