@@ -231,9 +231,10 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
     if (cam_id < mtx_feeds.size()) lck.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id]));
     MonoPlan plan;
     mono_begin(timestamp, img.cols, img.rows, cam_id, plan);
-    if (be->upload(plan.stream, plan.slot_cur, img.data, img.cols, img.rows, img.step) != FT_OK) return;
+    // through the pinned staging buffer; level 0 and the pyramid come out of one pass over it (no copy command)
+    if (be->stage_frame(plan.stream, plan.slot_cur, img.data, img.cols, img.rows, img.step) != FT_OK) return;
     const ft_lk_params prm = lk_params();
-    if (be->build_pyramid(1, &plan.stream, &plan.slot_cur, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
+    if (be->set_frames_staged_pyramid(1, &plan.stream, &plan.slot_cur, img.cols, img.rows, pyr_levels, win_size, win_size, nullptr) != FT_OK) return;
 
     const int cells = Grider_FAST::cells_for(img.cols, img.rows, grid_x, grid_y);
     const int kmax = per_cell_max();
