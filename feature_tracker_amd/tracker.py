@@ -194,6 +194,11 @@ class BatchTracker(_Base):
         self._keep = (getattr(self, "_keep", []) + [keep])[-6:]
         return self._feed(timestamps, 0, w, h, keep[0].strides[0], pipelined)
 
+    def feed_host_prepared(self, timestamps, host_ptrs, w, h, stride, pipelined=False):
+        """feed_host without per-call marshalling: ``timestamps`` a contiguous float64 array of n, ``host_ptrs`` a
+        ctypes (c_void_p * n) array of frame addresses (the caller keeps the frames alive)."""
+        return self._feed(timestamps, 0, w, h, stride, pipelined, ptrs=host_ptrs)
+
     def feed_device(self, timestamps, dev_ptrs, w, h, stride, pipelined=False):
         """dev_ptrs: n device addresses of frames resident in HBM.  pipelined=True leaves the last group's frame in
         flight (finish with flush()); the returned counts are those of the frames completed by the call."""
