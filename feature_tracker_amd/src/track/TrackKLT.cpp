@@ -393,7 +393,7 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
             J.stream_prev = img0.stream; J.slot_prev = img0.slot; J.stream_next = img1.stream; J.slot_next = img1.slot;
             J.n = (int)n; J.prev_xy = p0.data(); J.next_xy = p1.data(); J.status = mask.data(); J.err = err.data();
             ft_lk_params prm = lk_params();
-            prm.flags = FT_LK_USE_INITIAL_FLOW;   // the stereo association has no backward pass in the reference
+            prm.flags = FT_LK_USE_INITIAL_FLOW | FT_LK_NO_ERROR;   // the stereo association has no backward pass in the reference
             // optional: guess from the stereo extrinsics and known-E test (TrackMsckfVio.cpp:218-301) instead of "same pixel"
             double c0[8], c1[8], Rt[12];
             if (stereo_extrinsic_seed && stereo_Rt_of(cam_id_left, cam_id_right, Rt)) {
