@@ -226,7 +226,13 @@ struct ftk_group {
                 M.rc = batch->stage(N.ts.data(), N.frames.data());
             }
             if (M.rc == FT_OK) M.rc = batch->complete();
-            post_db();   // this set's observations go to the database on the writer thread
+            if (late_detect && posted.load(std::memory_order_acquire) == next) {
+                // one set at a time: a hundred or so observations are written faster here than a writer thread wakes up
+                wait_db();            // (sets handed to the writers earlier come first)
+                batch->flush_db();
+            } else {
+                post_db();   // this set's observations go to the database on the writer threads
+            }
             M.tracked = (long long)batch->tracked_features();
             M.attempted = (long long)batch->attempted_features();
             // sequentially consistent store/load pair: either the waiter sees `done` or this thread sees the waiter
