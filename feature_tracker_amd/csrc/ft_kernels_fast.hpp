@@ -113,20 +113,35 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
 
     // ---- stage pixels: a wavefront load covers 6 rows x 10 groups of 8 bytes; 3 rounds x 4 waves = 72 rows.
     //      Rows are clamped into the image and the group left of the image is clamped to column 0: only insets are
-    //      ever evaluated, and an inset pixel's circle lies inside the image.  Columns past the row end read on
-    //      into the next row of the plane (never used). ----
+    //      ever evaluated, and an inset pixel's circle lies inside the image.  No byte outside [0, w) of a row is
+    //      read: a group that straddles the row end is loaded from the last 8 bytes of the row and shifted into
+    //      place, a group past the row end is not loaded at all (the image may be a caller's buffer with stride w). ----
     {
         const int lane = t & 63, wv = t >> 6;
         const int rg = lane / FD_GROUPS, c8 = lane - rg * FD_GROUPS;
         const int gx = max(CX0 - 8 + 8 * c8, 0);
+        // 0: whole group inside the row, 1: straddles the row end (w >= 8), 2: nothing to load, 3: row shorter than a group
+        const int mode = gx + 8 <= G.w ? 0 : (gx >= G.w ? 2 : (G.w >= 8 ? 1 : 3));
+        const int ld_x = mode == 1 ? G.w - 8 : gx;
+        const uint32_t sh = mode == 1 ? 8u * (uint32_t)(gx - ld_x) : 0u;
         constexpr int SR = (FD_PROWS + 23) / 24;   // staging rounds: 4 waves x 6 rows each
         uint2 v[SR];
 #pragma unroll
         for (int k = 0; k < SR; k++) {
             const int row = min(wv * 6 + rg + 24 * k, FD_PROWS - 1);
             const int gy = min(max(OY - 4 + row, 0), G.h - 1);
-            const FdU2Unaligned u = *reinterpret_cast<const FdU2Unaligned*>(img + ((uint32_t)gy * pitch + (uint32_t)gx));
-            v[k] = make_uint2(u.a, u.b);
+            const uint8_t* src = img + ((uint32_t)gy * pitch + (uint32_t)ld_x);
+            if (mode <= 1) {
+                const FdU2Unaligned u = *reinterpret_cast<const FdU2Unaligned*>(src);
+                const uint64_t q = (((uint64_t)u.b << 32) | u.a) >> sh;
+                v[k] = make_uint2((uint32_t)q, (uint32_t)(q >> 32));
+            } else if (mode == 2) {
+                v[k] = make_uint2(0u, 0u);
+            } else {
+                uint64_t q = 0;
+                for (int b = 0; b < G.w - gx; b++) q |= (uint64_t)src[b] << (8 * b);
+                v[k] = make_uint2((uint32_t)q, (uint32_t)(q >> 32));
+            }
         }
 #pragma unroll
         for (int k = 0; k < SR; k++) {

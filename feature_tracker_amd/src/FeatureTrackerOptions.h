@@ -32,9 +32,10 @@ struct FeatureTrackerOptions {
     bool forward_backward = false;
     float fb_thresh = 1.0f;     // px
     bool speculative_detect = true;   // run the detector on every new frame so replenishment needs no extra sync
-    // outlier rejection after LK (the reference always does it, src/track/TrackKLT.cpp:405-424; here it is a switch
-    // because the sampling is this build's own and cannot reproduce OpenCV's inlier sets)
-    bool reject_outliers = false;
+    // outlier rejection after LK: on, as the reference always does it (src/track/TrackKLT.cpp:405-424).  The switch
+    // exists because the sampling is this build's own and cannot reproduce OpenCV's inlier sets point for point:
+    // off leaves mask_out = the LK status (and the forward-backward check)
+    bool reject_outliers = true;
     int ransac_hypotheses = 256;
     // left -> right association of new features as TrackMsckfVio::stereoMatch does it (src/track/TrackMsckfVio.cpp:218-301):
     // guess from the stereo extrinsics instead of "same pixel" (the TODO at src/track/TrackKLT.cpp:290-295), then the

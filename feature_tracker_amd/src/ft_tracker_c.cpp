@@ -375,14 +375,12 @@ int ftk_tracker_feed_imu(ftk_tracker* t, double timestamp, const double* am3, co
 int ftk_tracker_feed_stereo(ftk_tracker* t, double timestamp, const uint8_t* left, const uint8_t* right, int w, int h, size_t stride,
                             int cam_left, int cam_right) {
     if (!t || !left || !right || w < 1 || h < 1 || cam_left < 0 || cam_right < 0 || cam_left > 1 || cam_right > 1) return FT_E_INVALID;
-    t->trk->feed_stereo(timestamp, Image8(left, w, h, stride), Image8(right, w, h, stride), (size_t)cam_left, (size_t)cam_right);
-    return FT_OK;
+    return t->trk->feed_stereo(timestamp, Image8(left, w, h, stride), Image8(right, w, h, stride), (size_t)cam_left, (size_t)cam_right);
 }
 
 int ftk_tracker_feed_monocular(ftk_tracker* t, double timestamp, const uint8_t* img, int w, int h, size_t stride, int cam) {
     if (!t || !img || w < 1 || h < 1 || cam < 0 || cam > 1) return FT_E_INVALID;
-    t->trk->feed_monocular(timestamp, Image8(img, w, h, stride), (size_t)cam);
-    return FT_OK;
+    return t->trk->feed_monocular(timestamp, Image8(img, w, h, stride), (size_t)cam);
 }
 
 int ftk_tracker_get_points(ftk_tracker* t, int cam, float* xy, uint64_t* ids, int cap) {

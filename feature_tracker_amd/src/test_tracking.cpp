@@ -177,7 +177,11 @@ void feed_measurement_stereo() {
             continue;
         }
         const auto c0 = std::chrono::steady_clock::now();
-        trackFEATS->feed_stereo(stamps[ni], Image8(im_left.data(), wl, hl, (size_t)wl), Image8(im_right.data(), wr, hr, (size_t)wr), 0, 1);
+        const int frc = trackFEATS->feed_stereo(stamps[ni], Image8(im_left.data(), wl, hl, (size_t)wl), Image8(im_right.data(), wr, hr, (size_t)wr), 0, 1);
+        if (frc != FT_OK) {   // a device failure, not a lost track: stop instead of feeding on
+            std::cout << "feed_stereo failed with device error " << frc << " at " << left_files[ni] << std::endl;
+            break;
+        }
         const auto c1 = std::chrono::steady_clock::now();
         ms.push_back(std::chrono::duration<double, std::milli>(c1 - c0).count());
 
@@ -266,7 +270,7 @@ int write_dataset(const std::string& folder, int w, int h, int n_frames, int dis
 void usage() {
     std::cout << "test_tracking [--data FOLDER] [--config FILE] [--dump FILE] [--t-min S] [--t-max S]\n"
                  "              [--num-pts N] [--fast-threshold N] [--grid X Y] [--min-px-dist N]\n"
-                 "              [--win N] [--levels N] [--gyro-seed] [--forward-backward] [--reject-outliers]\n"
+                 "              [--win N] [--levels N] [--gyro-seed] [--forward-backward] [--no-reject-outliers]\n"
                  "              [--stereo-extrinsic-seed] [--device N]\n"
                  "test_tracking --write-dataset FOLDER [--size W H] [--frames N] [--disparity PX] [--seed N]\n"
                  "test_tracking --check-config FILE\n";
@@ -299,6 +303,7 @@ int main(int argc, char** argv) {
         else if (a == "--gyro-seed") params.use_gyro_seed = true;
         else if (a == "--forward-backward") params.forward_backward = true;
         else if (a == "--reject-outliers") params.reject_outliers = true;
+        else if (a == "--no-reject-outliers") params.reject_outliers = false;
         else if (a == "--stereo-extrinsic-seed") params.stereo_extrinsic_seed = true;
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
         else if (a == "--write-dataset") { need(1); write_folder = argv[++i]; }

@@ -67,7 +67,9 @@ public:
         }
     }
 
-    virtual void feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) = 0;
+    // Returns FT_OK or the first error code of the device layer (the reference's feed_stereo returns void,
+    // src/track/TrackBase.h:225: there the OpenCV calls throw instead).
+    virtual int feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) = 0;
 
     FeatureDatabase* get_feature_database() { return database.get(); }
 

@@ -226,15 +226,31 @@ void TrackKLT::mono_commit(MonoPlan& plan) {
     database->update_features(plan.db_ids.size(), plan.db_ids.data(), plan.timestamp, plan.cam, plan.db_uvn.data());
 }
 
-void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id) {
+int TrackKLT::abort_feed(int rc, size_t cam_a, size_t cam_b) {
+    (void)be->sync();   // nothing may be left waiting to be written into this object's buffers
+    spec_pending = false;
+    for (StereoDet& D : stereo_cache) D.valid = false;
+    cache_valid = false;
+    const size_t cam_ids[2] = {cam_a, cam_b};
+    for (size_t cam : cam_ids) {
+        pts_last[cam].clear(); ids_last[cam].clear();
+        cams[cam].slot_last = -1;
+    }
+    return rc;
+}
+
+int TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id) {
     std::unique_ptr<std::lock_guard<std::mutex>> lck;
     if (cam_id < mtx_feeds.size()) lck.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id]));
+    int rc;
+    // through the pinned staging buffer; level 0 and the pyramid come out of one pass over it (no copy command).
+    // The slot written is not the one holding the last pyramid, so a failure here leaves the tracker untouched.
+    const int stream_cur = stream0 + (int)cam_id, slot_cur = next_slot(cam_id);
+    if ((rc = be->stage_frame(stream_cur, slot_cur, img.data, img.cols, img.rows, img.step)) != FT_OK) return rc;
+    if ((rc = be->set_frames_staged_pyramid(1, &stream_cur, &slot_cur, img.cols, img.rows, pyr_levels, win_size, win_size, nullptr)) != FT_OK) return rc;
     MonoPlan plan;
     mono_begin(timestamp, img.cols, img.rows, cam_id, plan);
-    // through the pinned staging buffer; level 0 and the pyramid come out of one pass over it (no copy command)
-    if (be->stage_frame(plan.stream, plan.slot_cur, img.data, img.cols, img.rows, img.step) != FT_OK) return;
     const ft_lk_params prm = lk_params();
-    if (be->set_frames_staged_pyramid(1, &plan.stream, &plan.slot_cur, img.cols, img.rows, pyr_levels, win_size, win_size, nullptr) != FT_OK) return;
 
     const int cells = Grider_FAST::cells_for(img.cols, img.rows, grid_x, grid_y);
     const int kmax = per_cell_max();
@@ -253,11 +269,11 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
         if (need > 1 && cells > 0) {         // detector on the previous frame, only when needed (TrackKLT.cpp:271-275)
             const int per_cell = need / (grid_x * grid_y) + 1;
             last_buf.resize((size_t)cells * per_cell); last_cells.resize(cells);
-            if (be->fast_grid_async(1, &plan.stream, &plan.slot_last, threshold, grid_x, grid_y, per_cell, last_buf.data(),
-                                    (int)last_buf.size(), &last_n, last_cells.data()) == FT_OK && be->sync() == FT_OK) {
-                last_det.valid = true; last_det.per_cell = per_cell; last_det.cells = cells;
-                last_det.kps = last_buf.data(); last_det.n = last_n; last_det.cell_counts = last_cells.data();
-            }
+            if ((rc = be->fast_grid_async(1, &plan.stream, &plan.slot_last, threshold, grid_x, grid_y, per_cell, last_buf.data(),
+                                          (int)last_buf.size(), &last_n, last_cells.data())) != FT_OK || (rc = be->sync()) != FT_OK)
+                return abort_feed(rc, cam_id, cam_id);
+            last_det.valid = true; last_det.per_cell = per_cell; last_det.cells = cells;
+            last_det.kps = last_buf.data(); last_det.n = last_n; last_det.cell_counts = last_cells.data();
         }
     }
     ft_lk_job job;
@@ -265,24 +281,26 @@ void TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id
     bool want_cur_det = (speculative_detect || plan.first) && cells > 0;
     if (want_cur_det) {
         det_buf.resize((size_t)cells * kmax); det_cells.resize(cells);
-        want_cur_det = be->fast_grid_async(1, &plan.stream, &plan.slot_cur, threshold, grid_x, grid_y, kmax, det_buf.data(),
-                                           (int)det_buf.size(), &cur_n, det_cells.data()) == FT_OK;
+        if ((rc = be->fast_grid_async(1, &plan.stream, &plan.slot_cur, threshold, grid_x, grid_y, kmax, det_buf.data(),
+                                      (int)det_buf.size(), &cur_n, det_cells.data())) != FT_OK)
+            return abort_feed(rc, cam_id, cam_id);
     }
-    if (plan.run_lk && be->lk_track_async(1, &job, &prm) != FT_OK) plan.reset = true;
-    if (be->sync() != FT_OK) plan.reset = true;
+    if (plan.run_lk && (rc = be->lk_track_async(1, &job, &prm)) != FT_OK) return abort_feed(rc, cam_id, cam_id);
+    if ((rc = be->sync()) != FT_OK) return abort_feed(rc, cam_id, cam_id);
     if (want_cur_det) {
         cur_det.valid = true; cur_det.per_cell = kmax; cur_det.cells = cells;
         cur_det.kps = det_buf.data(); cur_det.n = cur_n; cur_det.cell_counts = det_cells.data();
     }
     mono_finish(plan, cur_det);
     mono_commit(plan);
+    return FT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // stereo path
 // ---------------------------------------------------------------------------------------------------------------
 
-void TrackKLT::perform_matching(std::vector<MatchJob>& jobs, const std::function<void()>& after_launch) {
+int TrackKLT::perform_matching(std::vector<MatchJob>& jobs, const std::function<void()>& after_launch) {
     const ft_lk_params prm = lk_params();
     struct Buf { std::vector<float> p0, p1, err; std::vector<uint8_t> st; double c0[8], c1[8]; };
     std::vector<Buf> bufs(jobs.size());
@@ -313,13 +331,14 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs, const std::function
         lk.push_back(J);
         lk_owner.push_back(j);
     }
-    if (lk.empty()) return;
-    if (be->lk_track_async((int)lk.size(), lk.data(), &prm) != FT_OK) return;
+    if (lk.empty()) return FT_OK;
+    int rc;
+    if ((rc = be->lk_track_async((int)lk.size(), lk.data(), &prm)) != FT_OK) return rc;
     // wait for the tracking results only: what the caller queues behind them keeps running after the wait
     uint64_t token = 0;
     const bool fenced = be->fence(&token) == FT_OK;
     if (after_launch) after_launch();
-    if ((fenced ? be->wait(token) : be->sync()) != FT_OK) return;
+    if ((rc = fenced ? be->wait(token) : be->sync()) != FT_OK) return rc;
     for (size_t q = 0; q < lk.size(); q++) {
         MatchJob& M = jobs[lk_owner[q]];
         Buf& B = bufs[lk_owner[q]];
@@ -329,12 +348,14 @@ void TrackKLT::perform_matching(std::vector<MatchJob>& jobs, const std::function
         M.mask_out->assign(B.st.begin(), B.st.end());
         for (size_t i = 0; i < n; i++) (*M.kpts1)[i].pt = Point2f(B.p1[2 * i], B.p1[2 * i + 1]);   // TrackKLT.cpp:427-430
     }
+    return FT_OK;
 }
 
-void TrackKLT::promote_stereo_detection() {
-    if (!spec_pending) return;
+int TrackKLT::promote_stereo_detection() {
+    if (!spec_pending) return FT_OK;
     spec_pending = false;
-    const bool ok = be->sync() == FT_OK;   // delivers the detector output if an earlier wait has not done so already
+    const int rc = be->sync();   // delivers the detector output if an earlier wait has not done so already
+    const bool ok = rc == FT_OK;
     for (int i = 0; i < 2; i++) {
         StereoDet& D = stereo_cache[i];
         D.valid = ok;
@@ -343,9 +364,10 @@ void TrackKLT::promote_stereo_detection() {
         D.kps.assign(spec_kps.begin() + (size_t)i * spec_cap, spec_kps.begin() + (size_t)i * spec_cap + spec_n[i]);
         D.cell_counts.assign(spec_cells.begin() + (size_t)i * spec_ncells, spec_cells.begin() + (size_t)(i + 1) * spec_ncells);
     }
+    return rc;
 }
 
-bool TrackKLT::grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out) {
+int TrackKLT::grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out) {
     for (const StereoDet& D : stereo_cache) {
         if (!D.valid || D.stream != img.stream || D.slot != img.slot || D.cols != img.cols || D.rows != img.rows) continue;
         // first num_needed/(grid_x*grid_y)+1 entries of every cell of the ranked lists, cells in index order: what
@@ -358,14 +380,16 @@ bool TrackKLT::grid_points(const DeviceImage& img, int num_needed, std::vector<K
             for (int r = 0; r < kept && r < k && off + r < D.n; r++) out.push_back(Grider_FAST::to_keypoint(D.kps[off + r]));
             off += kept;
         }
-        return true;
+        return FT_OK;
     }
-    return Grider_FAST::perform_griding(img, out, num_needed, grid_x, grid_y, threshold, true) == FT_OK;
+    if (Grider_FAST::cells_for(img.cols, img.rows, grid_x, grid_y) < 1) return FT_OK;   // image smaller than the grid: nothing to find
+    return Grider_FAST::perform_griding(img, out, num_needed, grid_x, grid_y, threshold, true);
 }
 
-void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
-                                        std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
-                                        size_t cam_id_left, size_t cam_id_right) {
+int TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
+                                       std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
+                                       size_t cam_id_left, size_t cam_id_right) {
+    int rc;
     Occupancy grid0(img0.cols, img0.rows, min_px_dist), grid1(img1.cols, img1.rows, min_px_dist);
     filter_by_occupancy(grid0, pts0, ids0);
     filter_by_occupancy(grid1, pts1, ids1);
@@ -374,7 +398,7 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
     const int num_featsneeded_0 = num_features - (int)pts0.size();
     if (num_featsneeded_0 > 1) {
         std::vector<KeyPoint> pts0_ext;
-        grid_points(img0, num_featsneeded_0, pts0_ext);
+        if ((rc = grid_points(img0, num_featsneeded_0, pts0_ext)) != FT_OK) return rc;
         std::vector<KeyPoint> kpts0_new;
         for (const KeyPoint& kpt : pts0_ext) {
             if (grid0.taken(kpt.pt)) continue;
@@ -400,8 +424,8 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
                 calib8_of(cam_id_left, c0); calib8_of(cam_id_right, c1);
                 J.calib_prev = c0; J.calib_next = c1; J.stereo_Rt = Rt;
             }
-            const bool ok = be->lk_track_async(1, &J, &prm) == FT_OK && be->sync() == FT_OK;
-            for (size_t i = 0; ok && i < n; i++) {
+            if ((rc = be->lk_track_async(1, &J, &prm)) != FT_OK || (rc = be->sync()) != FT_OK) return rc;
+            for (size_t i = 0; i < n; i++) {
                 const Point2f a(p0[2 * i], p0[2 * i + 1]), b(p1[2 * i], p1[2 * i + 1]);
                 const bool oob0 = a.x < 0 || a.y < 0 || a.x >= img0.cols || a.y >= img0.rows;
                 const bool oob1 = b.x < 0 || b.y < 0 || b.x >= img1.cols || b.y >= img1.rows;
@@ -425,7 +449,7 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
     const int num_featsneeded_1 = num_features - (int)pts1.size();
     if (num_featsneeded_1 > 1) {
         std::vector<KeyPoint> pts1_ext;
-        grid_points(img1, num_featsneeded_1, pts1_ext);
+        if ((rc = grid_points(img1, num_featsneeded_1, pts1_ext)) != FT_OK) return rc;
         for (const KeyPoint& kpt : pts1_ext) {
             if (grid1.taken(kpt.pt)) continue;
             pts1.push_back(kpt);
@@ -433,9 +457,10 @@ void TrackKLT::perform_detection_stereo(const DeviceImage& img0, const DeviceIma
             grid1.take(kpt.pt);
         }
     }
+    return FT_OK;
 }
 
-void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Image8& img_rightin, size_t cam_id_left, size_t cam_id_right) {
+int TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Image8& img_rightin, size_t cam_id_left, size_t cam_id_right) {
     std::unique_ptr<std::lock_guard<std::mutex>> lck1, lck2;
     if (cam_id_left < mtx_feeds.size()) lck1.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id_left]));
     if (cam_id_right < mtx_feeds.size() && cam_id_right != cam_id_left) lck2.reset(new std::lock_guard<std::mutex>(mtx_feeds[cam_id_right]));
@@ -445,21 +470,25 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     const int sl = stream0 + (int)cam_id_left, sr = stream0 + (int)cam_id_right;
     const int cur_l = cl.slot_last == 0 ? 1 : 0, cur_r = cr.slot_last == 0 ? 1 : 0;
 
-    // ingest both frames and build both pyramids (with gradients) in one batched launch per level (TrackKLT.cpp:45-58)
+    // ingest both frames and build both pyramids in one batched launch per level (TrackKLT.cpp:45-58).  The slots
+    // written are not the ones holding the last pair, so a failure in this part leaves the tracker as it was.
     const int streams[2] = {sl, sr}, slots[2] = {cur_l, cur_r};
+    int rc;
     if (img_leftin.cols == img_rightin.cols && img_leftin.rows == img_rightin.rows && sl != sr) {
         // both frames through the pinned staging buffers; level 0 and the pyramids come out of one pass over them
-        if (be->stage_frame(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
-        if (be->stage_frame(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
-        promote_stereo_detection();   // the previous pair's detector ran while the frames were copied
-        if (be->set_frames_staged_pyramid(2, streams, slots, img_leftin.cols, img_leftin.rows, pyr_levels, win_size, win_size, nullptr) != FT_OK) return;
+        if ((rc = be->stage_frame(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step)) != FT_OK) return rc;
+        if ((rc = be->stage_frame(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step)) != FT_OK) return rc;
+        // the previous pair's detector ran while the frames were copied
+        if ((rc = promote_stereo_detection()) != FT_OK) return abort_feed(rc, cam_id_left, cam_id_right);
+        if ((rc = be->set_frames_staged_pyramid(2, streams, slots, img_leftin.cols, img_leftin.rows, pyr_levels, win_size, win_size, nullptr)) != FT_OK) return rc;
     } else {
-        promote_stereo_detection();
-        if (be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step) != FT_OK) return;
-        if (be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step) != FT_OK) return;
-        if (be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
-        if (be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 0, nullptr) != FT_OK) return;
+        if ((rc = promote_stereo_detection()) != FT_OK) return abort_feed(rc, cam_id_left, cam_id_right);
+        if ((rc = be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step)) != FT_OK) return rc;
+        if ((rc = be->upload(sr, cur_r, img_rightin.data, img_rightin.cols, img_rightin.rows, img_rightin.step)) != FT_OK) return rc;
+        if ((rc = be->build_pyramid(1, streams, slots, pyr_levels, win_size, win_size, 0, nullptr)) != FT_OK) return rc;
+        if ((rc = be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 0, nullptr)) != FT_OK) return rc;
     }
+    frames_fed++;   // seeds the outlier rejection's sample sequence
     const DeviceImage cur_left{be, sl, cur_l, img_leftin.cols, img_leftin.rows};
     const DeviceImage cur_right{be, sr, cur_r, img_rightin.cols, img_rightin.rows};
     // speculative detection: the ranked detector of both new frames, whose output is what topping this pair up at the
@@ -477,10 +506,13 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
         spec_pending = be->fast_grid_async(2, streams, slots, threshold, grid_x, grid_y, spec_per_cell, spec_kps.data(), spec_cap,
                                            spec_n.data(), spec_cells.data()) == FT_OK;
     };
+    // the detector of this pair is queued at most once per call: a pair that was detected and promoted within this
+    // call (first call, tracking lost) has its ranked lists in the cache already
+    bool detected_now = false;
     auto roll = [&]() {
         cl.slot_last = cur_l; cl.cols = img_leftin.cols; cl.rows = img_leftin.rows; cl.t_last = timestamp;
         cr.slot_last = cur_r; cr.cols = img_rightin.cols; cr.rows = img_rightin.rows; cr.t_last = timestamp;
-        enqueue_spec();   // (already queued behind the tracking launch on the usual path)
+        if (!detected_now) enqueue_spec();   // (already queued behind the tracking launch on the usual path)
     };
     auto& ptsL = pts_last[cam_id_left];
     auto& ptsR = pts_last[cam_id_right];
@@ -490,16 +522,20 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     // first call, or tracking was lost: just extract (TrackKLT.cpp:63-72)
     if (ptsL.empty() || ptsR.empty() || cl.slot_last < 0 || cr.slot_last < 0) {
         enqueue_spec();
-        promote_stereo_detection();   // this pair's own detection is needed at once
-        perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right);
+        detected_now = spec_pending;
+        // this pair's own detection is needed at once
+        if ((rc = promote_stereo_detection()) != FT_OK) return abort_feed(rc, cam_id_left, cam_id_right);
+        if ((rc = perform_detection_stereo(cur_left, cur_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right)) != FT_OK)
+            return abort_feed(rc, cam_id_left, cam_id_right);
         roll();
-        return;
+        return FT_OK;
     }
 
     // top the previous pair up (TrackKLT.cpp:76-78)
     const DeviceImage last_left{be, sl, cl.slot_last, cl.cols, cl.rows};
     const DeviceImage last_right{be, sr, cr.slot_last, cr.cols, cr.rows};
-    perform_detection_stereo(last_left, last_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right);
+    if ((rc = perform_detection_stereo(last_left, last_right, ptsL, ptsR, idsL, idsR, cam_id_left, cam_id_right)) != FT_OK)
+        return abort_feed(rc, cam_id_left, cam_id_right);
 
     // temporal tracking of both cameras in one launch (TrackKLT.cpp:86-98)
     std::vector<uint8_t> mask_ll, mask_rr;
@@ -520,14 +556,14 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     std::vector<MatchJob> jobs(2);
     jobs[0] = MatchJob{last_left, cur_left, &ptsL, &pts_left_new, cam_id_left, cam_id_left, &mask_ll, seeded ? Hl : nullptr};
     jobs[1] = MatchJob{last_right, cur_right, &ptsR, &pts_right_new, cam_id_right, cam_id_right, &mask_rr, seeded ? Hr : nullptr};
-    perform_matching(jobs, enqueue_spec);
+    if ((rc = perform_matching(jobs, enqueue_spec)) != FT_OK) return abort_feed(rc, cam_id_left, cam_id_right);
 
     // not enough points: reset and re-detect next time (TrackKLT.cpp:118-129)
     if (mask_ll.empty() || mask_rr.empty()) {
         roll();
         ptsL.clear(); ptsR.clear(); idsL.clear(); idsR.clear();
         printf("[KLT-EXTRACTOR]: Failed to get enough points to do RANSAC, resetting.....\n");
-        return;
+        return FT_OK;
     }
 
     // merge: stereo tracks need both temporal tracks to succeed (TrackKLT.cpp:132-181)
@@ -578,6 +614,7 @@ void TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Ima
     roll();
     ptsL.swap(good_left); ptsR.swap(good_right);
     idsL.swap(good_ids_left); idsR.swap(good_ids_right);
+    return FT_OK;
 }
 
 }  // namespace feature_tracker

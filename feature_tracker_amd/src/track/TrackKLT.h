@@ -9,8 +9,8 @@
 //    pyramid, so that topping the previous frame up at the next call (src/track/TrackKLT.cpp:76-78) needs no extra
 //    device round trip; the per-cell lists are ranked, so truncating them to the count actually needed gives what
 //    the reference computes.
-// The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) is the option reject_outliers (a seeded
-// RANSAC of this build's own definition, off by default: then mask_out is the LK status).
+// The fundamental-matrix RANSAC after LK (src/track/TrackKLT.cpp:405-424) runs by default, as in the reference; it
+// is a seeded RANSAC of this build's own definition (option reject_outliers; off: mask_out is the LK status).
 #pragma once
 #include <functional>
 #include <vector>
@@ -56,10 +56,19 @@ public:
           fb_thresh(o.fb_thresh), speculative_detect(o.speculative_detect), reject_outliers(o.reject_outliers),
           ransac_hypotheses(o.ransac_hypotheses), stereo_extrinsic_seed(o.stereo_extrinsic_seed), stereo_threshold(o.stereo_threshold) {}
 
-    void feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) override;
+    // Both feeds return FT_OK or the first error code of the device layer.  A failure while the frame is being
+    // ingested (bad size, staging, pyramid launch) leaves the tracker as it was before the call.  A failure after
+    // that (tracking launch, device wait) drops the tracks and the last pyramid of the cameras involved, so that the
+    // next feed starts like a first frame; it is never reported as an ordinary "tracking lost" frame.
+    int feed_stereo(double timestamp, const Image8& img_left, const Image8& img_right, size_t cam_id_left, size_t cam_id_right) override;
 
     // single-camera variant of feed_stereo (the fork's upstream has one; the benchmark streams are monocular)
-    void feed_monocular(double timestamp, const Image8& img, size_t cam_id);
+    int feed_monocular(double timestamp, const Image8& img, size_t cam_id);
+
+    ~TrackKLT() override {
+        // the backend may still hold pointers into this object's detector buffers for a delivery that has not happened
+        if (spec_pending && be) (void)be->sync();
+    }
 
     // ---- staged monocular interface: lets a driver run many independent trackers through shared batched launches ----
     struct alignas(64) MonoPlan {
@@ -125,9 +134,9 @@ public:
 
 protected:
     // src/track/TrackKLT.cpp:223-368
-    void perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
-                                  std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
-                                  size_t cam_id_left = 0, size_t cam_id_right = 1);
+    int perform_detection_stereo(const DeviceImage& img0, const DeviceImage& img1, std::vector<KeyPoint>& pts0,
+                                 std::vector<KeyPoint>& pts1, std::vector<size_t>& ids0, std::vector<size_t>& ids1,
+                                 size_t cam_id_left = 0, size_t cam_id_right = 1);
     // monocular top-off: occupancy filter, then new points from a ranked detection
     void perform_detection_monocular(int cols, int rows, const Detection& det, std::vector<KeyPoint>& pts0, std::vector<size_t>& ids0);
     // src/track/TrackKLT.cpp:371-432 for one or two (img0 -> img1) pairs in one launch
@@ -140,7 +149,7 @@ protected:
         const float* H;
     };
     // after_launch (optional) runs between the tracking launch and the wait for its results
-    void perform_matching(std::vector<MatchJob>& jobs, const std::function<void()>& after_launch = nullptr);
+    int perform_matching(std::vector<MatchJob>& jobs, const std::function<void()>& after_launch = nullptr);
 
     // occupancy grid of (rows/min_px_dist+2) x (cols/min_px_dist+2) cells, first come wins (TrackKLT.cpp:230-263)
     struct Occupancy {
@@ -196,7 +205,7 @@ protected:
     bool forward_backward = false;
     float fb_thresh = 1.0f;
     bool speculative_detect = true;
-    bool reject_outliers = false;
+    bool reject_outliers = true;
     int ransac_hypotheses = 256;
     bool stereo_extrinsic_seed = false;
     double stereo_threshold = 3.0;
@@ -233,9 +242,12 @@ protected:
     std::vector<int> spec_n, spec_cells;
     bool spec_pending = false;
     int spec_per_cell = 0, spec_ncells = 0, spec_cap = 0, spec_cols = 0, spec_rows = 0, spec_stream[2] = {-1, -1}, spec_slot[2] = {-1, -1};
-    void promote_stereo_detection();
+    int promote_stereo_detection();
     // Grider_FAST::perform_griding(img, ..., num_needed, ...) from the cached detection of that image, or by a call
-    bool grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out);
+    int grid_points(const DeviceImage& img, int num_needed, std::vector<KeyPoint>& out);
+    // a device call failed after the frame's ingest: forget the tracks and last pyramids of these cameras and every
+    // cached or pending detection; returns rc
+    int abort_feed(int rc, size_t cam_a, size_t cam_b);
 
     // scratch for feed_monocular's own one-stream batch
     std::vector<ft_keypoint> det_buf;

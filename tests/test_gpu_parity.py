@@ -222,7 +222,8 @@ def test_lk_batched_jobs_and_gyro_seed(dev):
 
 @pytest.mark.parametrize("shape,grid,need,thr", [((480, 752), (5, 5), 150, 20), ((720, 1280), (9, 5), 2000, 20),
                                                   ((480, 752), (5, 5), 30, 10), ((240, 376), (7, 3), 400, 35),
-                                                  ((40, 59), (10, 2), 50, 20)])
+                                                  ((40, 59), (10, 2), 50, 20), ((479, 751), (5, 5), 150, 20),
+                                                  ((121, 63), (1, 1), 40, 12), ((64, 7), (1, 2), 10, 5)])
 def test_fast_grid_bit_exact(dev, shape, grid, need, thr):
     h, w = shape
     img = synth.texture(w, h, seed=80, n_shapes=400)
