@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the per-frame visual front-end hot path on MI355X.
 
-A step = one frame of every camera stream of the workload through the whole path: frame ingest from HBM, pyramid +
-Scharr gradients, grid FAST (replenishment), gyro-seeded pyramidal LK, host bookkeeping.  The frames are synthetic
-(seeded) and resident in HBM before the timed region starts.
+A step = one frame of every camera stream of the workload through the whole path: frame ingest, pyramid, grid FAST
+(replenishment), gyro-seeded pyramidal LK with the Scharr gradients evaluated in the kernel, fundamental-matrix outlier
+rejection, host bookkeeping and feature-database update.  The frames are synthetic (seeded).  For the headline
+`value` they are resident in HBM before the timed region starts; the same run also reports the rate with the frames
+handed over as host pointers (PCIe inside the clock) and the rate without the outlier rejection.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg5] [--scaling strong|weak]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; every rank runs its own streams (no
-collective in the data path, weak scaling) and rank 0 prints one JSON line with the whole-job rate.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run.  Nothing is exchanged in the data path.
+--scaling strong (default; BASELINE configs[3]): the workload's streams are dealt to the ranks, stream s on rank
+s mod N.  --scaling weak: every rank runs the workload's full stream count.  Rank 0 prints one JSON line with the
+whole-job rate.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -24,33 +29,34 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # the single-stream configuration: one 752x480 stream, 150 features, 21x21 window, 4 pyramid images, gyro seed
     "cfg2": dict(desc="1 x 752x480 stream, 150 features, maxLevel 3, win 21, gyro seed (latency-bound single stream)",
-                 streams=1, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1)),
+                 streams=1, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1), seq={}),
     # configs[2]: 1280x720, 2000 features, 4 levels, forward-backward
-    "cfg3": dict(desc="1 x 1280x720 stream, 2000 features, maxLevel 4, win 21, forward-backward check",
+    "cfg3": dict(desc="1 x 1280x720 stream, 2000 features, maxLevel 4, win 21, forward-backward check, grid 9x5",
                  streams=1, w=1280, h=720, opts=dict(num_pts=2000, win_size=21, pyr_levels=4, forward_backward=1, fb_thresh=1.0,
-                                                     grid_x=9, grid_y=5, use_gyro_seed=1)),
-    # configs[3]: 64 independent 752x480 streams batched (per GPU)
-    "cfg4": dict(desc="64 x 752x480 streams per GPU, 150 features each, maxLevel 3, win 21, gyro seed, batched launches",
-                 streams=64, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1)),
-    # configs[4]: 3840x2160, 10k features, 5 levels, replenishment every frame, one stream per GPU
-    "cfg5": dict(desc="1 x 3840x2160 stream per GPU, 10k features, maxLevel 5, win 21, replenishment every frame",
-                 streams=1, w=3840, h=2160, opts=dict(num_pts=10000, win_size=21, pyr_levels=5, grid_x=26, grid_y=15, use_gyro_seed=1)),
+                                                     grid_x=9, grid_y=5, use_gyro_seed=1), seq=dict(scene="blobs")),
+    # configs[3]: 64 independent 752x480 streams batched
+    "cfg4": dict(desc="64 x 752x480 streams, 150 features each, maxLevel 3, win 21, gyro seed, batched launches",
+                 streams=64, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1), seq={}),
+    # configs[4]: 3840x2160, 10k features, 5 levels, replenishment forced every frame (5 % of the tracks dropped per frame)
+    "cfg5": dict(desc="1 x 3840x2160 stream per GPU, 10k features, maxLevel 5, win 21, grid 26x15, 5 % of the tracks dropped "
+                      "every frame so that the detector replenishes on every frame",
+                 streams=1, w=3840, h=2160, opts=dict(num_pts=10000, win_size=21, pyr_levels=5, grid_x=26, grid_y=15, use_gyro_seed=1,
+                                                      drop_fraction=0.05), seq=dict(scene="blobs"), per_gpu=True),
 }
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 # HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
-# doubled as gfx950 requires; profiles/r1_h_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
+# doubled as gfx950 requires; profiles/*_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
 MEASURED_TRAFFIC = {
     ("cfg4", "lk_track"): (5817.7 + 19.9, "point"),
     ("cfg4", "pyramid"): (363195.0 + 460832.0 + 126840.5 + 28800.0, "frame"),
     ("cfg4", "fast_grid"): (374958.1 + 16713.3 + 5852.2 + 2709.2, "frame"),
 }
 
-
-# Vector-ALU instructions per wavefront-lane-group ("wave instructions") per unit of work, from a rocprofv3 SQ_INSTS_VALU
-# / SQ_WAVES pass over this workload (profiles/r1_j_pmc_insts.txt; level_kernel figures from r1_h_pmc_insts.txt, where they are not mixed with the gradient leg).  These kernels are bound by vector-instruction issue,
-# not by HBM: one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
+# Vector-ALU instructions per wavefront ("wave instructions") per unit of work, from a rocprofv3 SQ_INSTS_VALU / SQ_WAVES
+# pass over this workload (profiles/*_pmc_insts.txt).  These kernels are bound by vector-instruction issue, not by HBM:
+# one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
 MEASURED_VALU = {
     ("cfg4", "lk_track"): (4027.8, "point"),                                   # one wave per point
     ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
@@ -87,16 +93,23 @@ def lk_kernel_bytes(win, level_visits, iterations):
     return 5 * patch * level_visits + patch * iterations
 
 
-def make_sequences(wl, n_frames, rank, threads):
+def stream_ids_of_rank(wl, scaling, rank, world):
+    """Global stream ids (= sequence seeds) this rank runs.  Strong scaling deals the workload's streams round-robin
+    (stream s on rank s mod world); weak scaling, and workloads defined per GPU, give every rank the full count."""
+    from feature_tracker_amd.sharding import streams_of_rank, weak_scaling_stream_ids
+    if scaling == "strong" and not wl.get("per_gpu"):
+        return streams_of_rank(wl["streams"], world, rank)
+    return weak_scaling_stream_ids(wl["streams"], rank)
+
+
+def make_sequences(wl, n_frames, ids, threads):
     from feature_tracker_amd import synth
-    from feature_tracker_amd.sharding import weak_scaling_stream_ids
-    return [synth.Sequence(wl["w"], wl["h"], n_frames, stream_id=sid, threads=threads)
-            for sid in weak_scaling_stream_ids(wl["streams"], rank)]
+    return [synth.Sequence(wl["w"], wl["h"], n_frames, stream_id=sid, threads=threads, **wl.get("seq", {})) for sid in ids]
 
 
-def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0, n_groups=0, host_threads=0):
-    b = tracker_mod.BatchTracker(wl["streams"], wl["w"], wl["h"], device=device, lib_path=lib_path, n_groups=n_groups,
-                                 host_threads=host_threads, **wl["opts"])
+def setup_tracker(tracker_mod, wl, seqs, lib=None, device=0, n_groups=0, host_threads=0, **more_opts):
+    opts = dict(wl["opts"], **more_opts)
+    b = tracker_mod.BatchTracker(len(seqs), wl["w"], wl["h"], device=device, lib=lib, n_groups=n_groups, host_threads=host_threads, **opts)
     for s, q in enumerate(seqs):
         b.set_calibration(s, q.calib8, q.T_cam_imu)
         for t, g, a in zip(q.imu_t, q.gyro, q.accel):
@@ -104,36 +117,74 @@ def setup_tracker(tracker_mod, wl, seqs, lib_path=None, device=0, n_groups=0, ho
     return b
 
 
-def cpu_baseline(wl, seqs, threads, budget_s=20.0):
-    """The same orchestration on the CPU restatement of the reference path, on a bounded sample of the workload."""
-    import ctypes
+def cpu_baseline(wl, threads, budget_s=15.0):
+    """The same orchestration on the CPU restatement of the reference path (the checker build: test infrastructure,
+    used here only as the timed baseline), on a bounded sample of the workload: as many streams as host threads, as many
+    frames as fit the time budget."""
     from feature_tracker_amd import tracker
-    orc_dir = os.path.join(ROOT, "oracle")
-    path = os.path.join(orc_dir, "libft_oracle_tracker.so")
+    path = os.path.join(ROOT, "oracle", "libft_oracle_tracker.so")
     if not os.path.exists(path):
         return None
-    lib = ctypes.CDLL(path)
+    lib = tracker.bind(ctypes.CDLL(path))
     lib.fto_set_threads(threads)
-    n_streams = min(wl["streams"], max(1, threads))        # sample: as many streams as threads (one each), same shapes
-    sub = dict(wl, streams=n_streams)
-    # one stream group driven by the calling thread: the oracle's own worker threads are the only parallelism
-    b = setup_tracker(tracker, sub, seqs[:n_streams], lib_path=path, n_groups=1, host_threads=1)
-    n_frames = seqs[0].n_frames
-    ts = lambda i: [q.timestamps[i] for q in seqs[:n_streams]]
-    fr = lambda i: [q.frames[i] for q in seqs[:n_streams]]
-    b.feed_host(ts(0), fr(0))
-    b.feed_host(ts(1), fr(1))
+    n_streams = min(wl["streams"], max(1, threads))
+    # a first short run sizes the sample
+    probe_frames = 6
+    seqs = make_sequences(wl, probe_frames, [5000 + s for s in range(n_streams)], threads)
+    b = setup_tracker(tracker, wl, seqs, lib=lib, n_groups=1, host_threads=1)
+    b.feed_host([q.timestamps[0] for q in seqs], [q.frames[0] for q in seqs])
+    t0 = time.perf_counter()
+    for i in range(1, probe_frames):
+        b.feed_host([q.timestamps[i] for q in seqs], [q.frames[i] for q in seqs])
+    per_frame = (time.perf_counter() - t0) / (probe_frames - 1)
+    del b
+    n_frames = int(min(600, max(8, budget_s / max(per_frame, 1e-4)))) + 2
+    seqs = make_sequences(wl, n_frames, [5000 + s for s in range(n_streams)], threads)
+    b = setup_tracker(tracker, wl, seqs, lib=lib, n_groups=1, host_threads=1)
+    for i in range(2):
+        b.feed_host([q.timestamps[i] for q in seqs], [q.frames[i] for q in seqs])
     tracked, frames, t0 = 0, 0, time.perf_counter()
     for i in range(2, n_frames):
-        tr, _ = b.feed_host(ts(i), fr(i))
+        tr, _ = b.feed_host([q.timestamps[i] for q in seqs], [q.frames[i] for q in seqs])
         tracked += tr
         frames += 1
-        if time.perf_counter() - t0 > budget_s:
+        if time.perf_counter() - t0 > 2 * budget_s:
             break
     dt = time.perf_counter() - t0
     return dict(value=tracked / dt, unit="tracked_features/s", cores=threads, kind="port",
-                sample=f"{n_streams} stream(s) x {frames} frames of the same workload, {dt:.1f} s, whole path incl. host bookkeeping",
+                sample=f"{n_streams} stream(s) x {frames} frames of the same workload, {dt:.1f} s of wall time on {threads} threads, "
+                       "whole path incl. outlier rejection and host bookkeeping",
                 ms_per_frame=1e3 * dt / max(1, frames * n_streams))
+
+
+class Feeder:
+    """One tracker and the prepared per-step arguments of one feeding mode."""
+
+    def __init__(self, tracker_mod, wl, seqs, dev_frames, device, n_groups, host_threads, host_frames, **more_opts):
+        self.b = setup_tracker(tracker_mod, wl, seqs, device=device, n_groups=n_groups, host_threads=host_threads, **more_opts)
+        self.w, self.h, S = wl["w"], wl["h"], len(seqs)
+        n_frames = seqs[0].n_frames
+        self.host = host_frames
+        self.stamps = [np.ascontiguousarray([q.timestamps[i] for q in seqs], dtype=np.float64) for i in range(n_frames)]
+        if host_frames:
+            self.ptrs = [(ctypes.c_void_p * S)(*[q.frames[i].ctypes.data for q in seqs]) for i in range(n_frames)]
+        else:
+            self.ptrs = [(ctypes.c_void_p * S)(*[dev_frames[s][i].data_ptr() for s in range(S)]) for i in range(n_frames)]
+
+    def feed(self, i, pipelined=True):
+        if self.host:
+            return self.b.feed_host_prepared(self.stamps[i], self.ptrs[i], self.w, self.h, self.w, pipelined=pipelined)
+        return self.b.feed_device(self.stamps[i], self.ptrs[i], self.w, self.h, self.w, pipelined=pipelined)
+
+    def run(self, first, count):
+        """Feed `count` steps starting at frame `first`, pipelined, and complete them; returns (tracked, attempted)."""
+        tracked = attempted = 0
+        for i in range(first, first + count):
+            tr, at = self.feed(i)
+            tracked += tr
+            attempted += at
+        tr, at = self.b.flush()
+        return tracked + tr, attempted + at
 
 
 def main():
@@ -142,12 +193,14 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's streams dealt to the ranks (s mod N); weak = the full stream count on every rank")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; the first is `value`, all are reported")
     ap.add_argument("--groups", type=int, default=0, help="stream groups per GPU (0 = library default)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per GPU (0 = library default)")
-    ap.add_argument("--host-frames", action="store_true",
-                    help="feed frames from host memory (PCIe-inclusive rate; not the headline configuration)")
-    ap.add_argument("--reject-outliers", action="store_true",
-                    help="also run the fundamental-matrix outlier rejection after LK (not the headline configuration)")
+    ap.add_argument("--host-frames", action="store_true", help="headline leg fed from host memory (for profiling that leg alone)")
+    ap.add_argument("--no-reject-outliers", action="store_true", help="headline leg without the outlier rejection (for profiling)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-frame / no-rejection / gradient-image legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -176,28 +229,22 @@ def main():
 
     from feature_tracker_amd import device as ftdev
     from feature_tracker_amd import tracker
+    from feature_tracker_amd.sharding import reduce_run_totals
 
     wl = WORKLOADS[args.workload]
-    if args.reject_outliers:
-        wl = dict(wl, opts=dict(wl["opts"], reject_outliers=1), desc=wl["desc"] + " + outlier rejection")
-    K, W = args.steps, args.warmup
-    n_frames = W + K + 1                       # + the first frame, which only detects
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
+    n_frames = W + 1 + R * K                   # the first frame only detects
     threads = min(16, os.cpu_count() or 8)
+    ids = stream_ids_of_rank(wl, args.scaling, rank, world)
+    S = len(ids)
+    w, h = wl["w"], wl["h"]
     t_gen = time.perf_counter()
-    seqs = make_sequences(wl, n_frames, rank, threads)
+    seqs = make_sequences(wl, n_frames, ids, threads)
     t_gen = time.perf_counter() - t_gen
 
     # frames resident in HBM before anything is timed
-    S, w, h = wl["streams"], wl["w"], wl["h"]
     dev_frames = [torch.from_numpy(q.frames).to(dev) for q in seqs]
     torch.cuda.synchronize()
-    # per-step argument arrays prepared ahead: the timed loop then only calls into the library
-    import ctypes
-    ptrs = [(ctypes.c_void_p * S)(*[dev_frames[s][i].data_ptr() for s in range(S)]) for i in range(n_frames)]
-    stamps = [np.ascontiguousarray([q.timestamps[i] for q in seqs], dtype=np.float64) for i in range(n_frames)]
-
-    b = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=args.groups, host_threads=args.host_threads)
-    groups = b.groups()
 
     def barrier():
         torch.cuda.synchronize()
@@ -205,55 +252,95 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up in the same feeding mode as the timed steps (pipelined), completed before the clock starts
-    for i in range(W + 1):
-        if args.host_frames:
-            b.feed_host(stamps[i], [q.frames[i] for q in seqs], pipelined=True)
-        else:
-            b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
-    b.flush()
-    barrier()
-    b.stage_times(reset=True)
-    t0 = time.perf_counter()
-    tracked = attempted = 0
-    for i in range(W + 1, W + 1 + K):
-        # software-pipelined feed: the last stream group's frame completes during the next call (or in flush below)
-        if args.host_frames:
-            tr, at = b.feed_host(stamps[i], [q.frames[i] for q in seqs], pipelined=True)
-        else:
-            tr, at = b.feed_device(stamps[i], ptrs[i], w, h, w, pipelined=True)
-        tracked += tr
-        attempted += at
-    tr, at = b.flush()
-    tracked += tr
-    attempted += at
-    barrier()
-    dt = time.perf_counter() - t0
-    host_stages = b.stage_times()
+    def timed_leg(host_frames, **more_opts):
+        """W warm-up steps (plus the detecting first frame), then R timed regions of exactly K steps each, every
+        region bracketed by barrier + synchronize.  Returns the per-region (dt_max, tracked_all, attempted_all)."""
+        f = Feeder(tracker, wl, seqs, dev_frames, local_rank, args.groups, args.host_threads, host_frames, **more_opts) if S else None
+        if f:
+            f.run(0, W + 1)
+        regions = []
+        stages = None
+        for r in range(R):
+            barrier()
+            if f:
+                f.b.stage_times(reset=True)
+            t0 = time.perf_counter()
+            tr, at = f.run(W + 1 + r * K, K) if f else (0, 0)
+            barrier()
+            dt = time.perf_counter() - t0
+            if f and r == 0:
+                stages = f.b.stage_times()
+            dt_max, (tr_all, at_all) = reduce_run_totals(dt, [tr, at], device=dev if backend == "nccl" else None)
+            regions.append((dt_max, tr_all, at_all))
+        groups = f.b.groups() if f else 0
+        del f
+        return regions, stages, groups
 
-    # ---- per-kernel device time over the same K steps (HIP events on the tracker's own queue) ----
-    # One stream group (one device context, one queue) so that a kernel's events bracket that kernel alone.
-    lib = ftdev.load_library()
-    import ctypes as C
-    del b
-    b2 = setup_tracker(tracker, wl, seqs, device=local_rank, n_groups=1)
-    ctx2 = C.c_void_p(b2.group_ctx(0))
-    for i in range(W + 1):
-        b2.feed_device(stamps[i], ptrs[i], w, h, w)
-    lib.ft_profile(ctx2, 1)
-    for i in range(W + 1, W + 1 + K):
-        b2.feed_device(stamps[i], ptrs[i], w, h, w)
+    head_opts = dict(reject_outliers=0) if args.no_reject_outliers else {}
+    regions, host_stages, groups = timed_leg(args.host_frames, **head_opts)
+    dt_max, tracked_all, attempted_all = regions[0]
+    streams_total = S if not distributed else int(reduce_run_totals(0.0, [S], device=dev if backend == "nccl" else None)[1][0])
+
+    extra = {}
+    if world == 1 and not args.no_extra_legs and not args.host_frames and not args.no_reject_outliers:
+        # the same K steps with the frames handed over as host pointers (copied into pinned staging by the library's
+        # threads, level 0 built by a pass that reads the staging over the bus): PCIe inside the clock
+        rg, _, _ = timed_leg(True)
+        vals = [tr / dt for dt, tr, _ in rg]
+        extra["value_host_frames"] = vals[0]
+        extra["host_frames"] = dict(ms_per_step=1e3 * rg[0][0] / K, repeats=vals, pcie_gbs=S * w * h * K / rg[0][0] / 1e9,
+                                    note="frames passed as host pointers every step; PCIe-inclusive")
+        # ... and without the outlier rejection (mask = LK status), the configuration of the previous round's headline
+        rg, _, _ = timed_leg(False, reject_outliers=0)
+        vals = [tr / dt for dt, tr, _ in rg]
+        extra["value_without_outlier_rejection"] = vals[0]
+        extra["without_outlier_rejection"] = dict(ms_per_step=1e3 * rg[0][0] / K, repeats=vals)
+
+    # ---- per-kernel device time over the first region's K steps (HIP events on the tracker's own queue) ----
+    # One stream group (one device context, one queue), synchronous feeds, so that a kernel's events bracket that
+    # kernel alone.  The kernels launched are those of the timed leg (ft_profile mode 1 changes nothing but the
+    # events); the work counters of the tracking kernel come from a second, untimed pass (mode 2) over the same frames.
     kt = ftdev.ft_kernel_time()
-    lib.ft_kernel_times(ctx2, C.byref(kt), 1)
-    lib.ft_profile(ctx2, 0)
-
-    from feature_tracker_amd.sharding import reduce_run_totals
-    dt_max, (tracked_all, attempted_all) = reduce_run_totals(dt, [tracked, attempted], device=dev if backend == "nccl" else None)
+    ev_overhead_ms = 0.0
+    if rank == 0 and S:
+        lib = ftdev.load_library()
+        f2 = Feeder(tracker, wl, seqs, dev_frames, local_rank, 1, args.host_threads, args.host_frames, **head_opts)
+        ctx2 = ctypes.c_void_p(f2.b.group_ctx(0))
+        for i in range(W + 1):
+            f2.feed(i, pipelined=False)
+        lib.ft_profile(ctx2, 1)
+        for i in range(W + 1, W + 1 + K):
+            f2.feed(i, pipelined=False)
+        lib.ft_kernel_times(ctx2, ctypes.byref(kt), 1)
+        lib.ft_profile(ctx2, 0)
+        # what an event pair measures with nothing between its two records: subtracted from every group's time
+        ov = []
+        ms = ctypes.c_float()
+        for _ in range(30):
+            lib.ft_queue_time_begin(ctx2)
+            lib.ft_queue_time_end(ctx2, ctypes.byref(ms))
+            ov.append(ms.value)
+        ev_overhead_ms = float(np.median(ov))
+        del f2
+        f3 = Feeder(tracker, wl, seqs, dev_frames, local_rank, 1, args.host_threads, args.host_frames, **head_opts)
+        ctx3 = ctypes.c_void_p(f3.b.group_ctx(0))
+        for i in range(W + 1):
+            f3.feed(i, pipelined=False)
+        lib.ft_profile(ctx3, 2)
+        for i in range(W + 1, W + 1 + K):
+            f3.feed(i, pipelined=False)
+        kc = ftdev.ft_kernel_time()
+        lib.ft_kernel_times(ctx3, ctypes.byref(kc), 1)
+        lib.ft_profile(ctx3, 0)
+        del f3
+        kt.lk_points, kt.lk_level_visits, kt.lk_iterations = kc.lk_points, kc.lk_level_visits, kc.lk_iterations
 
     if rank == 0:
+        lv, win = wl["opts"]["pyr_levels"], wl["opts"]["win_size"]
+        fb = 2 if wl["opts"].get("forward_backward") else 1
         # algorithmic bytes per launch group (= one step of all streams of this GPU)
-        pyr_bytes = pyramid_kernel_bytes(w, h, wl["opts"]["pyr_levels"], with_gradients=False, with_ingest=not args.host_frames) * S
-        lk_bytes = lk_kernel_bytes(wl["opts"]["win_size"], kt.lk_level_visits, kt.lk_iterations) / max(1, kt.lk_launches)
+        pyr_bytes = pyramid_kernel_bytes(w, h, lv, with_gradients=False, with_ingest=not args.host_frames) * S
+        lk_bytes = lk_kernel_bytes(win, kt.lk_level_visits, kt.lk_iterations) / max(1, kt.lk_launches)
         kinds = {
             "pyramid": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
             "lk_track": (kt.lk_ms, kt.lk_launches, lk_bytes),
@@ -265,53 +352,66 @@ def main():
         per_kernel = {}
         for name, (ms, n, by) in kinds.items():
             if n:
-                avg = ms / n
-                e = dict(avg_ms=avg, launches=n, share_of_step=avg / (1e3 * dt / K))
+                avg = max(ms / n - ev_overhead_ms, 1e-6)
+                e = dict(avg_ms=avg, launches=n, share_of_step=avg / (1e3 * dt_max / K))
                 if by:
                     e.update(algorithmic_bytes=by, achieved_gbs=by / (avg * 1e-3) / 1e9, frac_hbm_peak=by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
                 per_kernel[name] = e
         if kt.lk_launches:
             per_kernel["lk_track"].update(points_per_launch=kt.lk_points / kt.lk_launches,
                                           level_visits_per_point=kt.lk_level_visits / max(1, kt.lk_points),
-                                          iterations_per_level_visit=kt.lk_iterations / max(1, kt.lk_level_visits))
+                                          iterations_per_level_visit=kt.lk_iterations / max(1, kt.lk_level_visits),
+                                          kernels_per_group=fb, note="forward + backward pass per launch group" if fb == 2 else None)
         # the roofline entry describes the kernel group that takes the most device time per step
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
         pk = per_kernel.get(dom, {})
         units = {"point": kt.lk_points / max(1, kt.lk_launches), "frame": float(S)}
+        plain = not (args.host_frames or args.no_reject_outliers) and world == 1
         for name, e in per_kernel.items():
-            m = MEASURED_TRAFFIC.get((args.workload, name)) if not args.host_frames else None
+            m = MEASURED_TRAFFIC.get((args.workload, name)) if plain else None
             e["hbm_traffic_bytes"] = m[0] * units[m[1]] if m else None
-            v = MEASURED_VALU.get((args.workload, name)) if not (args.host_frames or args.reject_outliers) else None
+            v = MEASURED_VALU.get((args.workload, name)) if plain else None
             if v:
                 e["valu_wave_insts"] = v[0] * units[v[1]]
                 e["valu_issue_frac"] = e["valu_wave_insts"] / (e["avg_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S
         roofline = dict(kernel=kernel_names.get(dom), bound="hbm", achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=pk.get("frac_hbm_peak"), traffic=pk.get("hbm_traffic_bytes"),
                         avg_launch_ms=pk.get("avg_ms"), algorithmic_bytes_per_launch=pk.get("algorithmic_bytes"),
+                        event_pair_overhead_ms=ev_overhead_ms,
+                        measured="HIP events on the context's queue, one stream group, the timed leg's kernels; the time of an "
+                                 "empty event pair is subtracted",
                         # what actually limits this kernel: vector-instruction issue (measured instruction count
                         # over the issue capacity of the device during the launch)
                         limiter="vector issue", valu_issue_frac=pk.get("valu_issue_frac"))
+        vals = [tr / dt for dt, tr, _ in regions]
         out = {
             "metric": "tracked_features_per_sec", "value": tracked_all / dt_max, "unit": "features/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "weak",
+            "steps": K, "warmup": W, "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True,
+            "scaling": "weak" if (args.scaling == "weak" or wl.get("per_gpu")) else "strong",
             "vs_baseline": None, "dtype": "u8/i16 images, i32 exact sums, f32 solve", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": S, "width": w, "height": h,
-                       "features_per_stream": wl["opts"]["num_pts"], "window": wl["opts"]["win_size"],
-                       "max_level": wl["opts"]["pyr_levels"], "frames_in_hbm": not args.host_frames},
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_total": streams_total, "streams_this_gpu": S,
+                       "width": w, "height": h, "features_per_stream": wl["opts"]["num_pts"], "window": win, "max_level": lv,
+                       "frames_in_hbm": not args.host_frames, "outlier_rejection": not args.no_reject_outliers,
+                       "forward_backward": bool(wl["opts"].get("forward_backward")), "drop_fraction": wl["opts"].get("drop_fraction", 0.0),
+                       "scene": wl.get("seq", {}).get("scene", "shapes")},
+            "repeats": {"values": vals, "min": min(vals), "median": float(np.median(vals)), "max": max(vals),
+                        "note": f"{R} consecutive timed regions of {K} steps; `value` is the first"},
             "tracked_fraction": tracked_all / max(1.0, attempted_all),
-            "frames_per_sec": world * S * K / dt_max,
+            "points_per_step": attempted_all / K,
+            "frames_per_sec": streams_total * K / dt_max,
             "roofline": roofline,
             "kernels": per_kernel,
             "host_stage_ms": host_stages,
             "stream_groups": groups,
             "setup": {"sequence_generation_s": t_gen},
         }
-        if not args.host_frames:
+        out.update(extra)
+        if world == 1 and not args.no_extra_legs and not args.host_frames:
             out["kernels"]["pyramid_gradient_build"] = pyramid_gradient_build(ftdev, wl, seqs, local_rank)
-        if not args.no_latency:
+        if not args.no_latency and world == 1:
             out["latency"] = single_stream_latency(tracker, local_rank)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on a single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(wl, seqs, threads)
+            out["cpu_baseline"] = cpu_baseline(wl, threads)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
@@ -323,7 +423,7 @@ def pyramid_gradient_build(ftdev, wl, seqs, device, reps=20):
     read once and its gradient image and the next level are written), all streams of one step per launch group.  This
     is the HBM-bound part of the path; the tracking pipeline itself evaluates the gradients inside the LK kernel and
     writes no gradient image."""
-    S, w, h, lv = wl["streams"], wl["w"], wl["h"], wl["opts"]["pyr_levels"]
+    S, w, h, lv = len(seqs), wl["w"], wl["h"], wl["opts"]["pyr_levels"]
     with ftdev.DeviceContext(w, h, max_levels=lv + 1, n_streams=S, n_slots=1, max_points=64, max_grid_cells=25, max_per_cell=2,
                              device=device) as ctx:
         for s in range(S):
@@ -331,12 +431,12 @@ def pyramid_gradient_build(ftdev, wl, seqs, device, reps=20):
         streams, slots = list(range(S)), [0] * S
         ctx.build_pyramid(streams, slots, lv, wl["opts"]["win_size"], with_gradients=True)
         ctx.sync()
-        ctx.profile(True)
+        ctx.profile(1)
         ctx.kernel_times()
         for _ in range(reps):
             ctx.build_pyramid(streams, slots, lv, wl["opts"]["win_size"], with_gradients=True)
         t = ctx.kernel_times()
-        ctx.profile(False)
+        ctx.profile(0)
     ms = t["pyramid_ms"] / max(1, t["pyramid_launches"])
     by = pyramid_kernel_bytes(w, h, lv, with_gradients=True, with_ingest=False) * S
     return dict(kernel="level_kernel with gradient images (one launch per level, all streams of one step)", avg_ms=ms, launches=reps,
@@ -350,7 +450,6 @@ def single_stream_latency(tracker, device, n=120):
     q = synth.Sequence(wl["w"], wl["h"], n + 10, stream_id=99)
     b = setup_tracker(tracker, wl, [q], device=device)
     # argument arrays prepared ahead, so that the clock brackets the library call and not the harness's marshalling
-    import ctypes
     w, h = wl["w"], wl["h"]
     ts = [np.ascontiguousarray([q.timestamps[i]], dtype=np.float64) for i in range(n + 10)]
     hp = [(ctypes.c_void_p * 1)(q.frames[i].ctypes.data) for i in range(n + 10)]
@@ -360,7 +459,7 @@ def single_stream_latency(tracker, device, n=120):
         b.feed_host_prepared(ts[i], hp[i], w, h, w)
         lat.append(time.perf_counter() - t0)
     lat = np.array(lat[10:]) * 1e3
-    out = {"workload": "cfg2: " + wl["desc"] + ", frame uploaded from host memory", "p50_ms": float(np.percentile(lat, 50)),
+    out = {"workload": "cfg2: " + wl["desc"] + ", frame uploaded from host memory, outlier rejection on", "p50_ms": float(np.percentile(lat, 50)),
            "p95_ms": float(np.percentile(lat, 95)), "frames": n}
     # the same stream with its frames in page-locked host memory: the level-0 pass reads them in place over the bus,
     # so the copy into the library's staging buffer drops out

@@ -118,7 +118,7 @@ struct ft_ctx {
     float* pf_dev = nullptr; float* pf_host = nullptr; size_t pf_points = 0;
 
     // timing
-    bool profile = false;
+    int profile = 0;   // bit 0: time kernel groups with events, bit 1: count LK work (iteration counters)
     std::vector<EventPair> ev_inflight;
     std::vector<EventPair> ev_pool;
     ft_kernel_time times{};
@@ -144,14 +144,14 @@ int slot_index(const ft_ctx* c, int stream, int slot) {
 }
 
 void prof_begin(ft_ctx* c, int kind, EventPair& ep) {
-    if (!c->profile) return;
+    if (!(c->profile & 1)) return;
     if (!c->ev_pool.empty()) { ep = c->ev_pool.back(); c->ev_pool.pop_back(); }
     else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
     ep.kind = kind;
     (void)hipEventRecord(ep.a, c->q);
 }
 void prof_end(ft_ctx* c, EventPair& ep) {
-    if (!c->profile || !ep.a) return;
+    if (!(c->profile & 1) || !ep.a) return;
     (void)hipEventRecord(ep.b, c->q);
     c->ev_inflight.push_back(ep);
 }
@@ -663,7 +663,8 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         if (J.iters) want_iters = true;
         if (J.stereo_Rt && J.n > 0) stereo = true;
     }
-    if (c->profile) want_iters = true;
+    const bool count_work = (c->profile & 2) != 0;
+    if (count_work) want_iters = true;   // the counters come from the per-level iteration table
     if (total > (size_t)c->lim.max_points) return FT_E_LIMIT;
     const int nlev = prm->max_level + 1;
 
@@ -803,7 +804,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     PendingLK& P = c->lk_pending;
     P.jobs.assign(jobs, jobs + n_jobs);
-    P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.count_work = c->profile; P.active = true;
+    P.total = (int)N; P.nlev = nlev; P.want_iters = want_iters; P.count_work = count_work; P.active = true;
     P.seq = ++c->seq;
     return FT_OK;
 }
@@ -1099,7 +1100,8 @@ int ft_wait(ft_ctx* c, uint64_t token) {
 
 int ft_profile(ft_ctx* c, int enable) {
     if (!c) return FT_E_INVALID;
-    c->profile = enable != 0;
+    if (enable < 0 || enable > 3) return FT_E_INVALID;
+    c->profile = enable;
     return FT_OK;
 }
 

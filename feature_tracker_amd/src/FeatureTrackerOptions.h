@@ -42,6 +42,10 @@ struct FeatureTrackerOptions {
     // known-essential-matrix test.  Needs both cameras' extrinsics.
     bool stereo_extrinsic_seed = false;
     double stereo_threshold = 3.0;   // px, src/track/TrackMsckfVio.h:217
+    // Forget this fraction of the active tracks at the start of every feed (chosen by a hash of feature id and frame
+    // count, so a run is repeatable), before the previous frame is topped up: forces detector replenishment on every
+    // frame whatever the scene does.  A load generator for benchmarks and tests; the reference has nothing like it.
+    double drop_fraction = 0.0;
 
     void print_trackers() const {
         printf("FEATURE TRACKING PARAMETERS:\n");

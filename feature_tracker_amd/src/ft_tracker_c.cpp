@@ -33,6 +33,7 @@ FeatureTrackerOptions to_options(const ftk_options& o) {
     r.forward_backward = o.forward_backward != 0; r.fb_thresh = o.fb_thresh; r.speculative_detect = o.speculative_detect != 0;
     r.reject_outliers = o.reject_outliers != 0; if (o.ransac_hypotheses > 0) r.ransac_hypotheses = o.ransac_hypotheses;
     r.stereo_extrinsic_seed = o.stereo_extrinsic_seed != 0; r.stereo_threshold = o.stereo_threshold;
+    r.drop_fraction = o.drop_fraction;
     return r;
 }
 
@@ -333,6 +334,7 @@ void ftk_default_options(ftk_options* o) {
     o->fb_thresh = d.fb_thresh; o->speculative_detect = d.speculative_detect;
     o->reject_outliers = d.reject_outliers; o->ransac_hypotheses = d.ransac_hypotheses;
     o->stereo_extrinsic_seed = d.stereo_extrinsic_seed; o->stereo_threshold = d.stereo_threshold;
+    o->drop_fraction = d.drop_fraction;
 }
 
 const char* ftk_backend_name(void) { return ftk_backend_label(); }

@@ -25,6 +25,22 @@ ft_lk_params TrackKLT::lk_params() const {
     return p;
 }
 
+void TrackKLT::drop_tracks(std::vector<KeyPoint>& pts, std::vector<size_t>& ids) const {
+    if (!(drop_fraction > 0.)) return;
+    const uint64_t limit = drop_fraction >= 1. ? ~0ull : (uint64_t)(drop_fraction * 18446744073709551616.0);
+    size_t o = 0;
+    for (size_t i = 0; i < pts.size(); i++) {
+        uint64_t z = (uint64_t)ids[i] * 0x9E3779B97F4A7C15ull + (uint64_t)frames_fed * 0xD1B54A32D192ED03ull;   // splitmix64 finalizer
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        if (z < limit) continue;
+        if (o != i) { pts[o] = pts[i]; ids[o] = ids[i]; }
+        o++;
+    }
+    pts.resize(o); ids.resize(o);
+}
+
 void TrackKLT::filter_by_occupancy(Occupancy& occ, std::vector<KeyPoint>& pts, std::vector<size_t>& ids) {
     size_t o = 0;
     for (size_t i = 0; i < pts.size(); i++) {
@@ -83,6 +99,7 @@ void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, M
     plan.prev_xy.clear(); plan.next_xy.clear(); plan.err.clear(); plan.status.clear(); plan.db_ids.clear(); plan.db_uvn.clear();
     plan.cam = cam_id;
     frames_fed++;
+    drop_tracks(pts_last[cam_id], ids_last[cam_id]);
     plan.timestamp = timestamp;
     plan.stream = stream0 + (int)cam_id;
     plan.slot_last = cs.slot_last;
@@ -489,6 +506,8 @@ int TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Imag
         if ((rc = be->build_pyramid(1, streams + 1, slots + 1, pyr_levels, win_size, win_size, 0, nullptr)) != FT_OK) return rc;
     }
     frames_fed++;   // seeds the outlier rejection's sample sequence
+    drop_tracks(pts_last[cam_id_left], ids_last[cam_id_left]);
+    if (cam_id_right != cam_id_left) drop_tracks(pts_last[cam_id_right], ids_last[cam_id_right]);
     const DeviceImage cur_left{be, sl, cur_l, img_leftin.cols, img_leftin.rows};
     const DeviceImage cur_right{be, sr, cur_r, img_rightin.cols, img_rightin.rows};
     // speculative detection: the ranked detector of both new frames, whose output is what topping this pair up at the

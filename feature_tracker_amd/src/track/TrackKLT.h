@@ -54,7 +54,8 @@ public:
           grid_y(o.grid_y), min_px_dist(o.min_px_dist), pyr_levels(o.pyr_levels), win_size(o.win_size), lk_max_iter(o.lk_max_iter),
           lk_eps(o.lk_eps), lk_min_eig(o.lk_min_eig), use_gyro_seed(o.use_gyro_seed), forward_backward(o.forward_backward),
           fb_thresh(o.fb_thresh), speculative_detect(o.speculative_detect), reject_outliers(o.reject_outliers),
-          ransac_hypotheses(o.ransac_hypotheses), stereo_extrinsic_seed(o.stereo_extrinsic_seed), stereo_threshold(o.stereo_threshold) {}
+          ransac_hypotheses(o.ransac_hypotheses), stereo_extrinsic_seed(o.stereo_extrinsic_seed), stereo_threshold(o.stereo_threshold),
+          drop_fraction(o.drop_fraction) {}
 
     // Both feeds return FT_OK or the first error code of the device layer.  A failure while the frame is being
     // ingested (bad size, staging, pyramid launch) leaves the tracker as it was before the call.  A failure after
@@ -209,6 +210,9 @@ protected:
     int ransac_hypotheses = 256;
     bool stereo_extrinsic_seed = false;
     double stereo_threshold = 3.0;
+    double drop_fraction = 0.0;
+    // forget drop_fraction of the tracks (same ids in every camera list handed in during one feed)
+    void drop_tracks(std::vector<KeyPoint>& pts, std::vector<size_t>& ids) const;
     unsigned frames_fed = 0;   // seeds the outlier rejection's sample sequence: every frame draws other samples
     int slot_ring = 2;
     // per-tracker scratch reused every frame (no allocation in the steady state)

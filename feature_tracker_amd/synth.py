@@ -22,6 +22,8 @@ def _load():
         L = C.CDLL(LIB_PATH)
         L.fts_canvas.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.fts_canvas.restype = None
+        L.fts_canvas_blobs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.fts_canvas_blobs.restype = None
         L.fts_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_uint32, C.c_int]
         L.fts_frame.restype = None
@@ -32,6 +34,13 @@ def _load():
 def canvas(cw, ch, seed, n_waves=64, n_shapes=400, threads=8):
     out = np.empty((ch, cw), dtype=np.uint8)
     _load().fts_canvas(out.ctypes.data, cw, ch, seed, n_waves, n_shapes, threads)
+    return out
+
+
+def canvas_blobs(cw, ch, seed, n_waves=64, spacing=18.0, jitter=3.5, threads=8):
+    """Canvas for the feature-dense configurations: a jittered lattice of small blobs, one strong corner each."""
+    out = np.empty((ch, cw), dtype=np.uint8)
+    _load().fts_canvas_blobs(out.ctypes.data, cw, ch, seed, n_waves, float(spacing), float(jitter), threads)
     return out
 
 
@@ -47,13 +56,19 @@ def frame(cnv, w, h, cx, cy, theta, sigma=2.0, noise_seed=0, threads=8, out=None
 class Sequence:
     """One camera stream: frames, timestamps, gyro samples and calibration."""
 
-    def __init__(self, w, h, n_frames, stream_id=0, fps=20.0, sigma=2.0, imu_hz=200.0, threads=8, shapes_per_mpx=280):
+    def __init__(self, w, h, n_frames, stream_id=0, fps=20.0, sigma=2.0, imu_hz=200.0, threads=8, shapes_per_mpx=280,
+                 scene="shapes", blob_spacing=18.0, blob_jitter=3.5):
+        """scene "shapes": random filled rectangles and discs (a few hundred corners per 752x480 frame);
+        scene "blobs": a jittered lattice of small blobs for the configurations that track thousands of features."""
         self.w, self.h, self.n_frames, self.fps = w, h, n_frames, fps
         seed = 12345 + stream_id
         rng = np.random.default_rng(seed)
         cw, ch = 2 * w, 2 * h
-        n_shapes = max(50, int(shapes_per_mpx * cw * ch / 1e6))
-        cnv = canvas(cw, ch, seed, 64, n_shapes, threads)
+        if scene == "blobs":
+            cnv = canvas_blobs(cw, ch, seed, 64, blob_spacing, blob_jitter, threads)
+        else:
+            n_shapes = max(50, int(shapes_per_mpx * cw * ch / 1e6))
+            cnv = canvas(cw, ch, seed, 64, n_shapes, threads)
         # smooth trajectory: two incommensurate sinusoids per axis, peak speed about 6 px/frame
         k = np.arange(n_frames)
         w1, w2 = 2 * np.pi / rng.uniform(55, 75), 2 * np.pi / rng.uniform(30, 45)

@@ -1,5 +1,7 @@
 """ctypes binding of include/ft_tracker.h: the host tracker layer (TrackKLT / TrackKLTBatch) on the gfx950 device
-library.  ``lib_path`` exists so that the test-suite can drive the identical wrapper over its CPU checker build."""
+library.  ``load_library`` knows one library only, the product's; there is no fallback.  The classes accept an already
+bound library object (``bind``) so that a harness can drive the identical wrapper over another build of the same C
+interface."""
 import ctypes as C
 import os
 
@@ -15,7 +17,7 @@ class ftk_options(C.Structure):
                 ("lk_eps", C.c_double), ("lk_min_eig", C.c_double), ("use_gyro_seed", C.c_int), ("forward_backward", C.c_int),
                 ("fb_thresh", C.c_float), ("speculative_detect", C.c_int),
                 ("reject_outliers", C.c_int), ("ransac_hypotheses", C.c_int),
-                ("stereo_extrinsic_seed", C.c_int), ("stereo_threshold", C.c_double)]
+                ("stereo_extrinsic_seed", C.c_int), ("stereo_threshold", C.c_double), ("drop_fraction", C.c_double)]
 
 
 SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "ftk_tracker_set_calibration",
@@ -24,19 +26,23 @@ SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "
            "ftk_batch_set_calibration", "ftk_batch_feed_imu", "ftk_batch_feed", "ftk_batch_feed_pipelined", "ftk_batch_flush", "ftk_batch_get_points", "ftk_batch_database_size", "ftk_batch_get_track", "ftk_batch_groups", "ftk_batch_group_ctx",
            "ftk_batch_stage_times", "ftk_batch_device_ctx", "ftk_backend_name"]
 
-_libs = {}
+_lib = None
 
 
-def load_library(lib_path=None):
-    path = lib_path or LIB_PATH
-    if path in _libs:
-        return _libs[path]
-    if not os.path.exists(path):
-        raise ImportError(f"{path} is missing: build it first (__graft_entry__.build()); there is no fallback")
-    if lib_path is None:
+def load_library():
+    """The product library (libft_tracker.so on libft_device.so); raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it first (__graft_entry__.build()); there is no fallback")
         from . import device
         device.load_library()      # maps the HIP runtime and libft_device.so first
-    L = C.CDLL(path)
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(L):
+    """Declare the argument types of the ftk_* interface on a loaded library and return it."""
     vp, dp = C.c_void_p, C.POINTER(C.c_double)
     L.ftk_default_options.argtypes = [C.POINTER(ftk_options)]
     L.ftk_default_options.restype = None
@@ -70,7 +76,6 @@ def load_library(lib_path=None):
     L.ftk_batch_device_ctx.restype = vp
     L.ftk_backend_name.argtypes = []
     L.ftk_backend_name.restype = C.c_char_p
-    _libs[path] = L
     return L
 
 
@@ -97,8 +102,8 @@ class _Base:
 class Tracker(_Base):
     """One TrackKLT with cameras 0 and 1 (reference driver usage: src/test_tracking.cpp:229-231,:148,:207)."""
 
-    def __init__(self, max_width, max_height, device=0, lib_path=None, **options):
-        self.lib = load_library(lib_path)
+    def __init__(self, max_width, max_height, device=0, lib=None, **options):
+        self.lib = lib if lib is not None else load_library()
         self.opts = make_options(self.lib, **options)
         self._h = C.c_void_p()
         self._check(self.lib.ftk_tracker_create(C.byref(self._h), device, C.byref(self.opts), max_width, max_height), "ftk_tracker_create")
@@ -154,8 +159,8 @@ class Tracker(_Base):
 class BatchTracker(_Base):
     """n independent monocular streams through shared batched launches (TrackKLTBatch)."""
 
-    def __init__(self, n_streams, max_width, max_height, device=0, lib_path=None, n_groups=0, host_threads=0, **options):
-        self.lib = load_library(lib_path)
+    def __init__(self, n_streams, max_width, max_height, device=0, lib=None, n_groups=0, host_threads=0, **options):
+        self.lib = lib if lib is not None else load_library()
         self.opts = make_options(self.lib, **options)
         self.n = n_streams
         self._h = C.c_void_p()

@@ -129,8 +129,8 @@ typedef struct ft_kernel_time {
     double pyramid_ms;   int pyramid_launches;    /* fused pyrDown + Scharr level kernel */
     double lk_ms;        int lk_launches;
     double fast_ms;      int fast_launches;       /* score + nms/compact + top-k, per ft_fast_grid call */
-    /* LK work done while profiling: points tracked, (point, level) pairs whose template was evaluated, and Newton
-     * iterations summed over them (from the kernel's own per-level counters) */
+    /* LK work done while ft_profile mode 2 is on: points tracked, (point, level) pairs whose template was evaluated,
+     * and Newton iterations summed over them (from the kernel's own per-level counters) */
     long long lk_points, lk_level_visits, lk_iterations;
 } ft_kernel_time;
 
@@ -226,8 +226,11 @@ int ft_sync(ft_ctx* ctx);
 int ft_fence(ft_ctx* ctx, uint64_t* token);
 int ft_wait(ft_ctx* ctx, uint64_t token);
 
-/* Timing. ft_profile(1) brackets every kernel group with HIP events on the context's queue (adds a little
- * overhead); ft_kernel_times reads and optionally resets the totals.  ft_queue_time_* time a whole region. */
+/* Timing. ft_profile(ctx, mode): mode 1 brackets every kernel group with HIP events on the context's queue (adds a
+ * little overhead; the kernels launched are exactly those of an unprofiled run); mode 2 counts the LK work instead
+ * (points, level visits, Newton iterations: the tracking kernel then also writes its per-level iteration table, so its
+ * time is not representative); 3 = both; 0 = off.  ft_kernel_times reads and optionally resets the totals.
+ * ft_queue_time_* time a whole region. */
 int ft_profile(ft_ctx* ctx, int enable);
 int ft_kernel_times(ft_ctx* ctx, ft_kernel_time* out, int reset);
 int ft_queue_time_begin(ft_ctx* ctx);

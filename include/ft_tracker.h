@@ -36,6 +36,8 @@ typedef struct ftk_options {
     int stereo_extrinsic_seed;  /* left -> right association seeded from the stereo extrinsics + known-E test,
                                    src/track/TrackMsckfVio.cpp:218-301 -> off ("same pixel", src/track/TrackKLT.cpp:290-295) */
     double stereo_threshold;    /* px, src/track/TrackMsckfVio.h:217 -> 3 */
+    double drop_fraction;       /* load generator, no reference counterpart: forget this fraction of the active tracks at the
+                                   start of every feed so that the detector must replenish on every frame -> 0 */
 } ftk_options;
 
 typedef struct ftk_tracker ftk_tracker;

@@ -12,12 +12,15 @@ import torch.distributed as dist
 
 from feature_tracker_amd import sharding, synth, tracker
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+
 ORC = os.path.join(ROOT, "oracle", "libft_oracle_tracker.so")
 
 
 def track_streams(stream_ids, n_frames, w, h):
     seqs = [synth.Sequence(w, h, n_frames, stream_id=s) for s in stream_ids]
-    b = tracker.BatchTracker(len(seqs), w, h, lib_path=ORC, n_groups=1, host_threads=1, num_pts=60, win_size=15, pyr_levels=2, use_gyro_seed=1)
+    b = tracker.BatchTracker(len(seqs), w, h, lib=O.checker_tracker_lib(), n_groups=1, host_threads=1, num_pts=60, win_size=15, pyr_levels=2, use_gyro_seed=1)
     for s, q in enumerate(seqs):
         b.set_calibration(s, q.calib8, q.T_cam_imu)
         for t, g, a in zip(q.imu_t, q.gyro, q.accel):

@@ -21,6 +21,19 @@ class fto_lk_params(C.Structure):
 
 
 _lib = None
+_checker_tracker = None
+TRACKER_LIB = os.path.join(ORACLE_DIR, "libft_oracle_tracker.so")
+
+
+def checker_tracker_lib():
+    """The host tracker layer compiled against this oracle as its backend (oracle/libft_oracle_tracker.so), bound with
+    the product's own ctypes declarations: tests hand it to feature_tracker_amd.tracker's classes as ``lib=``."""
+    global _checker_tracker
+    if _checker_tracker is None:
+        lib()   # builds the oracle libraries if need be
+        from feature_tracker_amd import tracker
+        _checker_tracker = tracker.bind(C.CDLL(TRACKER_LIB))
+    return _checker_tracker
 
 
 def lib():

@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle_lib as O
 from feature_tracker_amd import tracker
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -146,7 +147,7 @@ def test_checker_driver_equals_python_driven_tracker(tmp_path, flags, opts):
     run = _read_dump(dump)
 
     # the same files through the C interface of the tracker
-    t = tracker.Tracker(320, 240, lib_path=ORC, **opts)
+    t = tracker.Tracker(320, 240, lib=O.checker_tracker_lib(), **opts)
     f = 0.61 * 320
     k = [f, f, 159.5, 119.5, 0, 0, 0, 0]
     T0, T1 = np.eye(4), np.eye(4)
@@ -166,7 +167,7 @@ def test_checker_driver_equals_python_driven_tracker(tmp_path, flags, opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [(), ("--gyro-seed", "--win", "21", "--forward-backward"), ("--reject-outliers", "--stereo-extrinsic-seed")])
+@pytest.mark.parametrize("flags", [(), ("--gyro-seed", "--win", "21", "--forward-backward"), ("--reject-outliers", "--stereo-extrinsic-seed"), ("--no-reject-outliers",)])
 def test_product_driver_equals_checker_driver(tmp_path, flags):
     d = _dataset(tmp_path, 752, 480, 8)
     a, b = str(tmp_path / "gpu.txt"), str(tmp_path / "cpu.txt")

@@ -35,15 +35,41 @@ def _same_run(a, b):
             assert np.abs(xy_a - xy_b).max(initial=0) <= 0.01  # px
 
 
-@pytest.mark.parametrize("opts", [dict(win_size=21, use_gyro_seed=1), dict(win_size=15, speculative_detect=0),
+@pytest.mark.parametrize("opts", [dict(win_size=21, use_gyro_seed=1), dict(win_size=15, speculative_detect=0, reject_outliers=0),
                                   dict(win_size=21, forward_backward=1, fb_thresh=1.0, pyr_levels=4, num_pts=400, grid_x=8, grid_y=5)])
 def test_batch_tracker_matches_cpu_checker(opts):
     O.lib()
     seqs = [synth.Sequence(752, 480, 10, stream_id=s) for s in range(3)]
     gpu = _feed_all(tracker.BatchTracker(3, 752, 480, **opts), seqs, 10)
-    cpu = _feed_all(tracker.BatchTracker(3, 752, 480, lib_path=ORC, **opts), seqs, 10)
+    cpu = _feed_all(tracker.BatchTracker(3, 752, 480, lib=O.checker_tracker_lib(), **opts), seqs, 10)
     _same_run(gpu, cpu)
     assert gpu[-1][0] > 250
+
+
+@pytest.mark.parametrize("name,w,h,opts,min_pts", [
+    # BASELINE configs[2]: 1280x720, 2000 features, maxLevel 4, forward-backward, grid 9x5 (cells of about 150 px)
+    ("cfg3", 1280, 720, dict(num_pts=2000, win_size=21, pyr_levels=4, forward_backward=1, fb_thresh=1.0, grid_x=9, grid_y=5, use_gyro_seed=1), 1900),
+    # BASELINE configs[4]: 3840x2160, 10k features, maxLevel 5, grid 26x15, replenishment forced on every frame
+    ("cfg5", 3840, 2160, dict(num_pts=10000, win_size=21, pyr_levels=5, grid_x=26, grid_y=15, use_gyro_seed=1, drop_fraction=0.05), 9500),
+])
+def test_full_size_configurations_match_cpu_checker(name, w, h, opts, min_pts):
+    """The two large configurations exactly as the benchmark runs them (same options, same scene, outlier rejection
+    on), four frames: every frame's attempted and tracked counts, ids and positions equal the CPU checker's, and the
+    number of points handed to LK stays at or above 95 % of num_pts."""
+    O.lib()
+    q = synth.Sequence(w, h, 4, stream_id=11, scene="blobs")
+    import ctypes
+    O.checker_tracker_lib().fto_set_threads(8)
+    gpu = _feed_all(tracker.BatchTracker(1, w, h, **opts), [q], 4)
+    cpu = _feed_all(tracker.BatchTracker(1, w, h, lib=O.checker_tracker_lib(), n_groups=1, host_threads=1, **opts), [q], 4)
+    O.checker_tracker_lib().fto_set_threads(1)
+    _same_run(gpu, cpu)
+    for tr, at, _ in gpu[1:]:
+        assert at >= min_pts and tr >= 0.9 * at
+    if opts.get("drop_fraction"):
+        # dropped tracks really are replaced: new ids appear on every frame
+        for (_, _, a), (_, _, b) in zip(gpu[1:], gpu[2:]):
+            assert len(np.setdiff1d(b[0][1], a[0][1])) >= 0.03 * min_pts
 
 
 def test_batch_tracker_with_outlier_rejection_matches_cpu_checker():
@@ -55,20 +81,20 @@ def test_batch_tracker_with_outlier_rejection_matches_cpu_checker():
         q.frames = tsynth.with_moving_patches(q.frames, seed=s)
     opts = dict(win_size=21, use_gyro_seed=1, reject_outliers=1)
     gpu = _feed_all(tracker.BatchTracker(3, 752, 480, **opts), seqs, 8)
-    cpu = _feed_all(tracker.BatchTracker(3, 752, 480, lib_path=ORC, **opts), seqs, 8)
+    cpu = _feed_all(tracker.BatchTracker(3, 752, 480, lib=O.checker_tracker_lib(), **opts), seqs, 8)
     _same_run(gpu, cpu)
-    loose = _feed_all(tracker.BatchTracker(3, 752, 480, win_size=21, use_gyro_seed=1), seqs, 2)
+    loose = _feed_all(tracker.BatchTracker(3, 752, 480, win_size=21, use_gyro_seed=1, reject_outliers=0), seqs, 2)
     assert gpu[1][1] == loose[1][1] and gpu[1][0] <= loose[1][0] - 20   # the patches' features went
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(reject_outliers=1), dict(stereo_extrinsic_seed=1),
+@pytest.mark.parametrize("opts", [dict(), dict(reject_outliers=0), dict(stereo_extrinsic_seed=1, reject_outliers=0),
                                   dict(stereo_extrinsic_seed=1, stereo_threshold=0.4, reject_outliers=1)])
 def test_stereo_tracker_matches_cpu_checker(opts):
     O.lib()
     q = synth.Sequence(640, 400, 8, stream_id=7)
     runs = []
-    for lib_path in (None, ORC):
-        t = tracker.Tracker(640, 400, lib_path=lib_path, win_size=15, **opts)
+    for lib in (None, O.checker_tracker_lib()):
+        t = tracker.Tracker(640, 400, lib=lib, win_size=15, **opts)
         T_right = q.T_cam_imu.copy()
         T_right[0, 3] += 0.11                     # sideways baseline, used by the extrinsic seed / known-E test
         t.set_calibration(np.stack([q.calib8, q.calib8]), np.stack([q.T_cam_imu, T_right]))
@@ -151,7 +177,7 @@ def test_late_detector_with_streams_that_lose_tracking():
     seqs[2].frames[7] = 10             # stream 2 for one
     opts = dict(win_size=15, pyr_levels=2, num_pts=80, use_gyro_seed=1)
     gpu = _feed_all(tracker.BatchTracker(3, 376, 240, **opts), seqs, n_frames)
-    cpu = _feed_all(tracker.BatchTracker(3, 376, 240, lib_path=ORC, **opts), seqs, n_frames)
+    cpu = _feed_all(tracker.BatchTracker(3, 376, 240, lib=O.checker_tracker_lib(), **opts), seqs, n_frames)
     _same_run(gpu, cpu)
     assert len(gpu[5][2][0][0]) == 0 and len(gpu[7][2][0][0]) > 40      # lost, then found again
     # pipelined, two groups: the detector runs before the tracking launch there

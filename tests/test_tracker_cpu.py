@@ -20,7 +20,7 @@ def seq():
 
 
 def _run(seq, n_frames=20, **opts):
-    b = tracker.BatchTracker(1, seq.w, seq.h, lib_path=ORC, **opts)
+    b = tracker.BatchTracker(1, seq.w, seq.h, lib=O.checker_tracker_lib(), **opts)
     b.set_calibration(0, seq.calib8, seq.T_cam_imu)
     for t, g, a in zip(seq.imu_t, seq.gyro, seq.accel):
         b.feed_imu(0, t, a, g)
@@ -120,7 +120,7 @@ def test_outlier_rejection_drops_independently_moving_features(seq):
     frames = tsynth.with_moving_patches(seq.frames[:8])
 
     def run(**opts):
-        b = tracker.BatchTracker(1, seq.w, seq.h, lib_path=ORC, win_size=21, **opts)
+        b = tracker.BatchTracker(1, seq.w, seq.h, lib=O.checker_tracker_lib(), win_size=21, **opts)
         b.set_calibration(0, seq.calib8, seq.T_cam_imu)
         return [b.feed_host([seq.timestamps[i]], [frames[i]]) for i in range(8)]
 
@@ -134,7 +134,7 @@ def test_outlier_rejection_drops_independently_moving_features(seq):
 
 
 def test_stereo_feed_tracks_both_cameras_and_fills_database(seq):
-    t = tracker.Tracker(seq.w, seq.h, lib_path=ORC, win_size=15)
+    t = tracker.Tracker(seq.w, seq.h, lib=O.checker_tracker_lib(), win_size=15)
     t.set_calibration(np.stack([seq.calib8, seq.calib8]), np.stack([seq.T_cam_imu, seq.T_cam_imu]))
     # right camera = left image shifted by 4 px (a fronto-parallel plane): stereo tracks must be found
     for i in range(8):
@@ -158,8 +158,8 @@ def test_stereo_feed_tracks_both_cameras_and_fills_database(seq):
     assert np.allclose(uv[:, 2], (uv[:, 0] - seq.calib8[2]) / seq.calib8[0], atol=1e-5)
 
 
-def _stereo_run(seq, right_of, lib_path, n_frames=6, **opts):
-    t = tracker.Tracker(seq.w, seq.h, lib_path=lib_path, win_size=15, **opts)
+def _stereo_run(seq, right_of, lib, n_frames=6, **opts):
+    t = tracker.Tracker(seq.w, seq.h, lib=lib, win_size=15, **opts)
     T_right = seq.T_cam_imu.copy()
     T_right[0, 3] += 0.11                         # sideways baseline: t_cam0_cam1 = (0.11, 0, 0)
     t.set_calibration(np.stack([seq.calib8, seq.calib8]), np.stack([seq.T_cam_imu, T_right]))
@@ -181,14 +181,14 @@ def test_stereo_extrinsic_seed_accepts_row_disparity_and_rejects_column_disparit
     def common(h):
         return len(np.intersect1d(h[-1][1], h[-1][3]))
 
-    assert common(_stereo_run(seq, along, ORC, stereo_extrinsic_seed=1)) > 60
-    assert common(_stereo_run(seq, across, ORC, stereo_extrinsic_seed=1)) <= 3          # (a track that slid along an edge may pass)
-    assert common(_stereo_run(seq, across, ORC)) > 60
-    assert common(_stereo_run(seq, across, ORC, stereo_extrinsic_seed=1, stereo_threshold=0.0)) > 60   # seed only, no test
+    assert common(_stereo_run(seq, along, O.checker_tracker_lib(), stereo_extrinsic_seed=1)) > 60
+    assert common(_stereo_run(seq, across, O.checker_tracker_lib(), stereo_extrinsic_seed=1)) <= 3          # (a track that slid along an edge may pass)
+    assert common(_stereo_run(seq, across, O.checker_tracker_lib())) > 60
+    assert common(_stereo_run(seq, across, O.checker_tracker_lib(), stereo_extrinsic_seed=1, stereo_threshold=0.0)) > 60   # seed only, no test
 
 
 def test_mono_tracker_class_matches_batch_of_one(seq):
-    t = tracker.Tracker(seq.w, seq.h, lib_path=ORC, win_size=21)
+    t = tracker.Tracker(seq.w, seq.h, lib=O.checker_tracker_lib(), win_size=21)
     t.set_calibration(np.stack([seq.calib8, seq.calib8]))
     hist = _run(seq, 8, win_size=21)
     for i in range(8):
@@ -201,7 +201,7 @@ def test_pipelined_grouped_feed_equals_plain_feed():
     seqs = [synth.Sequence(376, 240, 8, stream_id=20 + s) for s in range(8)]
 
     def run(pipelined, n_groups):
-        b = tracker.BatchTracker(8, 376, 240, lib_path=ORC, n_groups=n_groups, win_size=15, num_pts=80)
+        b = tracker.BatchTracker(8, 376, 240, lib=O.checker_tracker_lib(), n_groups=n_groups, win_size=15, num_pts=80)
         for s, q in enumerate(seqs):
             b.set_calibration(s, q.calib8, q.T_cam_imu)
         total = 0
@@ -290,8 +290,8 @@ def test_stereo_speculative_detection_equals_detection_on_demand(seq, opts):
     blanked = type("S", (), dict(w=seq.w, h=seq.h, frames=frames, timestamps=seq.timestamps, calib8=seq.calib8, T_cam_imu=seq.T_cam_imu,
                                  imu_t=seq.imu_t, gyro=seq.gyro, accel=seq.accel))
     right_of = lambda f: np.roll(f, -5, axis=1)
-    a = _stereo_run(blanked, right_of, ORC, n_frames=9, speculative_detect=1, **opts)
-    b = _stereo_run(blanked, right_of, ORC, n_frames=9, speculative_detect=0, **opts)
+    a = _stereo_run(blanked, right_of, O.checker_tracker_lib(), n_frames=9, speculative_detect=1, **opts)
+    b = _stereo_run(blanked, right_of, O.checker_tracker_lib(), n_frames=9, speculative_detect=0, **opts)
     for fa, fb in zip(a, b):
         for xa, xb in zip(fa, fb):
             assert np.array_equal(xa, xb)

@@ -6,10 +6,10 @@ import numpy as np
 from feature_tracker_amd import synth, tracker
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC = os.path.join(ROOT, "oracle", "libft_oracle_tracker.so")
-lib = ctypes.CDLL(ORC); lib.fto_set_threads(8)
+lib = tracker.bind(ctypes.CDLL(ORC)); lib.fto_set_threads(8)
 S, n_frames = 16, 40
 seqs = [synth.Sequence(376, 240, n_frames, stream_id=s) for s in range(S)]
-b = tracker.BatchTracker(S, 376, 240, lib_path=ORC, win_size=15, pyr_levels=2, n_groups=1, host_threads=1, num_pts=150, use_gyro_seed=1)
+b = tracker.BatchTracker(S, 376, 240, lib=lib, win_size=15, pyr_levels=2, n_groups=1, host_threads=1, num_pts=150, use_gyro_seed=1)
 for s, q in enumerate(seqs):
     b.set_calibration(s, q.calib8, q.T_cam_imu)
     for t, g, a in zip(q.imu_t, q.gyro, q.accel):

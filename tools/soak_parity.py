@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import synth as tsynth
 from feature_tracker_amd import synth, tracker
+import oracle_lib as O
 ORC = os.path.join(ROOT, "oracle", "libft_oracle_tracker.so")
 N_FRAMES = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 CASES = [
@@ -22,8 +23,8 @@ for name, w, h, opts, patches in CASES:
         for s, q in enumerate(seqs):
             q.frames = tsynth.with_moving_patches(q.frames, seed=s, size=64)
     runs = []
-    for lib_path in (None, ORC):
-        b = tracker.BatchTracker(3, w, h, lib_path=lib_path, **opts)
+    for lib in (None, O.checker_tracker_lib()):
+        b = tracker.BatchTracker(3, w, h, lib=lib, **opts)
         for s, q in enumerate(seqs):
             b.set_calibration(s, q.calib8, q.T_cam_imu)
             for t, g, a in zip(q.imu_t, q.gyro, q.accel):
