@@ -345,10 +345,13 @@ def main():
             "pyramid": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
             "lk_track": (kt.lk_ms, kt.lk_launches, lk_bytes),
             "fast_grid": (kt.fast_ms, kt.fast_launches, w * h * S),
+            # per point: both positions and the status in, the normalized pair out and in again, the results out
+            "outlier_rejection": (kt.reject_ms, kt.reject_launches, 66 * kt.lk_points / max(1, kt.lk_launches)),
         }
         kernel_names = {"pyramid": "level_kernel (frame ingest + pyrDown, one launch per level, all streams of one step)",
                         "lk_track": "lk_kernel (template + Newton iterations, all levels, all features of one step)",
-                        "fast_grid": "fast_detect_kernel + fast_topk_kernel (all streams of one step)"}
+                        "fast_grid": "fast_detect_kernel + fast_topk_kernel (all streams of one step)",
+                        "outlier_rejection": "ransac_kernel (undistortion, hypotheses, inlier counts, final mask; one workgroup per stream)"}
         per_kernel = {}
         for name, (ms, n, by) in kinds.items():
             if n:

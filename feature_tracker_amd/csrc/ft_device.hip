@@ -36,7 +36,7 @@ struct SlotState {
 
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
-    int kind = 0;   // 0 pyramid, 1 lk, 2 fast
+    int kind = 0;   // 0 pyramid, 1 lk, 2 fast, 3 outlier rejection
 };
 
 struct PendingLK {
@@ -91,7 +91,6 @@ struct ft_ctx {
     uint8_t* lk_out_host = nullptr; uint8_t* lk_out_dev = nullptr; size_t lk_out_bytes = 0;
     uint8_t* lk_out_host_dev = nullptr;   // device-side address of lk_out_host
     float4* lk_norm_dev = nullptr;        // outlier rejection: normalized point pairs
-    RansacPartial* ransac_part_dev = nullptr;   // outlier rejection: best model of every workgroup
     // descriptor matching, allocated on first use: both descriptor sets and both neighbour tables, device + pinned host
     uint8_t* match_dev = nullptr;  uint8_t* match_host = nullptr;  size_t match_cap = 0;   // descriptors per set
     PendingLK lk_pending;
@@ -163,7 +162,8 @@ void prof_collect(ft_ctx* c) {
         if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             if (ep.kind == 0) { c->times.pyramid_ms += ms; c->times.pyramid_launches++; }
             else if (ep.kind == 1) { c->times.lk_ms += ms; c->times.lk_launches++; }
-            else { c->times.fast_ms += ms; c->times.fast_launches++; }
+            else if (ep.kind == 2) { c->times.fast_ms += ms; c->times.fast_launches++; }
+            else { c->times.reject_ms += ms; c->times.reject_launches++; }
         }
         c->ev_pool.push_back(ep);
     }
@@ -243,8 +243,10 @@ int sync_and_deliver(ft_ctx* c) {
 }
 
 void launch_reject(ft_ctx* c, const OutlierArgs& o, int n_jobs) {
-    hipLaunchKernelGGL(ransac_hypotheses_kernel, dim3(n_jobs * RO_WG_PER_JOB), dim3(256), 0, c->q, o, c->ransac_part_dev);
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_jobs), dim3(256), 0, c->q, o, c->ransac_part_dev);
+    EventPair ep;
+    prof_begin(c, 3, ep);
+    hipLaunchKernelGGL(ransac_kernel, dim3(n_jobs), dim3(256), 0, c->q, o);
+    prof_end(c, ep);
 }
 
 int pick_seglen(int win_w, int win_h) {
@@ -415,8 +417,6 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lk_out_dev = (uint8_t*)p;
     if (hipMalloc(&p, sizeof(float4) * N) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_norm_dev = (float4*)p;
-    if (hipMalloc(&p, sizeof(RansacPartial) * RO_WG_PER_JOB * FT_MAX_BATCH) != hipSuccess) return fail(FT_E_NOMEM);
-    c->ransac_part_dev = (RansacPartial*)p;
 
     // FAST scratch
     c->cand_entries_per_img = ((size_t)lim->max_width + 2 * 64) * ((size_t)lim->max_height + 2 * 64) / 4 + (size_t)lim->max_grid_cells;
@@ -466,7 +466,6 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
-    if (c->ransac_part_dev) (void)hipFree(c->ransac_part_dev);
     if (c->match_dev) (void)hipFree(c->match_dev);
     if (c->match_host) (void)hipHostFree(c->match_host);
     if (c->cand) (void)hipFree(c->cand);

@@ -7,14 +7,15 @@
 // is the build's own (a counter-based hash); model, error measure and threshold are OpenCV's.  The arithmetic is
 // double precision in a fixed order, so the result equals the CPU checker's bit for bit.
 //
-// Two launches per batch of image pairs:
-//   ransac_hypotheses_kernel  eight workgroups per image pair, 32 hypotheses each.  A hypothesis is solved by eight
-//                             lanes, one per equation of the 8x9 system, each holding its row in registers; pivot
-//                             search and the pivot row travel by lane shuffles, so the elimination touches no
-//                             memory.  The inlier count of the 32 models is then shared by all 256 threads
-//                             (32 models x 8 slices of the point set, points read from LDS).
-//   ransac_select_kernel      one workgroup per image pair: best of the eight partial winners, final mask, and the
-//                             batch results (positions, residuals, status) written into the pinned host block.
+// One launch per batch of image pairs, one workgroup per pair (ransac_kernel).  Hypotheses are tried in index order in
+// rounds of 32.  A hypothesis is solved by eight lanes, one per equation of the 8x9 system, each holding its row in
+// registers; pivot search and the pivot row travel by lane shuffles, so the elimination touches no memory.  The inlier
+// counts of a round's 32 models are shared by all 256 threads (32 models x 8 slices of the point set, points read from
+// LDS).  After every round one thread walks its models in index order exactly as a sequential loop would: a model with
+// more inliers than the best so far becomes the best and lowers the number of hypotheses still to be tried to the
+// smallest N with (1 - w^8)^N <= 0.001, w = its inlier ratio (the adaptive iteration count that the confidence argument
+// 0.999 of cv::findFundamentalMat stands for); models past that number are ignored.  The same workgroup then writes the
+// final mask and the batch results (positions, residuals, status) into the pinned host block.
 #pragma once
 #include "ft_kernels_lk.hpp"
 
@@ -75,15 +76,25 @@ __device__ __forceinline__ bool ro_inlier(const double* F, float4 m, float thr2)
     return err <= thr2;
 }
 
-constexpr int RO_HYP_PER_WG = 32;     // hypotheses per workgroup (8 lanes each)
-constexpr int RO_WG_PER_JOB = 8;      // 8 x 32 = 256 hypotheses at most
+constexpr int RO_HYP_PER_WG = 32;     // hypotheses per round (8 lanes each)
 constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest is read from the global copy
 
-struct RansacPartial {   // best model of one workgroup
-    int count;           // inliers, -1 = none with at least 8
-    int hyp;             // hypothesis index
-    double F[9];
-};
+// Hypotheses to try before a sample of eight inliers has been drawn with probability 0.999, given the best model so far
+// has `inliers` of n points: the smallest N with (1 - w^8)^N <= 0.001, at most max_h.  Plain multiplications in a fixed
+// order (no pow, no log), so the CPU checker gets the same number.
+__device__ inline int ro_hypotheses_needed(int inliers, int n, int max_h) {
+    const double w = (double)inliers / (double)n;
+    const double w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
+    const double q = 1. - w8;
+    double p = 1.;
+    int N = 0;
+    while (N < max_h) {
+        p = p * q;
+        N++;
+        if (p <= 0.001) break;
+    }
+    return N;
+}
 
 // element j of a nine-element register array (a macro on purpose: behind a function boundary the compiler turns the
 // select chain into an indexed load and the array moves to scratch memory)
@@ -91,167 +102,149 @@ struct RansacPartial {   // best model of one workgroup
     ((j) == 8 ? (v)[8] : (j) == 7 ? (v)[7] : (j) == 6 ? (v)[6] : (j) == 5 ? (v)[5] : (j) == 4 ? (v)[4] : (j) == 3 ? (v)[3] \
      : (j) == 2 ? (v)[2] : (j) == 1 ? (v)[1] : (v)[0])
 
-__global__ void __launch_bounds__(256) ransac_hypotheses_kernel(OutlierArgs a, RansacPartial* __restrict__ part) {
+__global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
     __shared__ float4 nl[RO_NORM_LDS];
     __shared__ double Fs[RO_HYP_PER_WG][9];
+    __shared__ double best_F[9];
     __shared__ int valid[RO_HYP_PER_WG];
     __shared__ int cnt[RO_HYP_PER_WG];
+    __shared__ int s_stop, s_best, s_have;
     const int t = threadIdx.x;
-    const int job_i = blockIdx.x / RO_WG_PER_JOB, h0 = (blockIdx.x % RO_WG_PER_JOB) * RO_HYP_PER_WG;
-    const LKJobDev* job = a.jobs + job_i;
+    const LKJobDev* job = a.jobs + blockIdx.x;
     const int first = job->first, n = job->count;
-    RansacPartial* out = part + blockIdx.x;
-    if (n < 8 || h0 >= a.hypotheses) {   // uniform for the workgroup
-        if (t == 0) { out->count = -1; out->hyp = h0; }
-        return;
-    }
     const double* c0 = job->calib;        // template image camera
     const double* c1 = job->calib + 8;    // target image camera
+    const double f0 = c0[0] < c0[1] ? c0[1] : c0[0], f1 = c1[0] < c1[1] ? c1[1] : c1[0];
+    const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
 
-    // ---- normalized coordinates of both point sets (every workgroup of the pair writes the same values) ----
+    // ---- normalized coordinates of both point sets ----
     for (int i = t; i < n; i += 256) {
         const float2 p = ro_undistort(a.prev_xy[2 * (first + i)], a.prev_xy[2 * (first + i) + 1], c0);
         const float2 q = ro_undistort(a.next_xy[2 * (first + i)], a.next_xy[2 * (first + i) + 1], c1);
         const float4 m = make_float4(p.x, p.y, q.x, q.y);
-        a.norm[first + i] = m;
         if (i < RO_NORM_LDS) nl[i] = m;
+        else a.norm[first + i] = m;
     }
-    if (t < RO_HYP_PER_WG) cnt[t] = 0;
+    if (t == 0) { s_stop = n < 8 ? 0 : a.hypotheses; s_best = 7; s_have = 0; }   // a model needs at least 8 inliers
     __syncthreads();   // also orders this workgroup's global writes above before its reads below
 
-    const double f0 = c0[0] < c0[1] ? c0[1] : c0[0], f1 = c1[0] < c1[1] ? c1[1] : c1[0];
-    const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
-
-    // ---- one hypothesis per eight lanes, lane r holds equation r ----
-    {
-        const int r = t & 7, hl = t >> 3, h = h0 + hl;
-        const int gbase = (t & 63) & ~7;
-        int mine = 0;
+    for (int h0 = 0; h0 < s_stop; h0 += RO_HYP_PER_WG) {   // s_stop only changes between the barriers at the loop's end
+        if (t < RO_HYP_PER_WG) cnt[t] = 0;
+        // ---- one hypothesis per eight lanes, lane r holds equation r ----
         {
-            int idx[8];
-            uint32_t draw = 0;
+            const int r = t & 7, hl = t >> 3, h = h0 + hl;
+            const int gbase = (t & 63) & ~7;
+            int mine = 0;
+            {
+                int idx[8];
+                uint32_t draw = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                for (;;) {
-                    const uint32_t rnd = ro_mix32(a.seed ^ ro_mix32((uint32_t)h * 0x9E3779B9u + 0x85EBCA6Bu * draw));
-                    draw++;
-                    const int cand = (int)(rnd % (uint32_t)n);
-                    bool dup = false;
+                for (int k = 0; k < 8; k++) {
+                    for (;;) {
+                        const uint32_t rnd = ro_mix32(a.seed ^ ro_mix32((uint32_t)h * 0x9E3779B9u + 0x85EBCA6Bu * draw));
+                        draw++;
+                        const int cand = (int)(rnd % (uint32_t)n);
+                        bool dup = false;
 #pragma unroll
-                    for (int q = 0; q < 8; q++) dup |= (q < k) && idx[q] == cand;
-                    if (!dup) {
+                        for (int q = 0; q < 8; q++) dup |= (q < k) && idx[q] == cand;
+                        if (!dup) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) idx[q] = (q == k) ? cand : idx[q];
-                        break;
+                            for (int q = 0; q < 8; q++) idx[q] = (q == k) ? cand : idx[q];
+                            break;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 8; k++) mine = (r == k) ? idx[k] : mine;
+                for (int k = 0; k < 8; k++) mine = (r == k) ? idx[k] : mine;
+            }
+            const float4 m = mine < RO_NORM_LDS ? nl[mine] : a.norm[first + mine];
+            const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
+            double A[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.};
+            uint32_t colmask = 0;
+            bool row_used = false, ok = true;
+            int my_pc = 0;
+#pragma unroll
+            for (int step = 0; step < 8; step++) {
+                // largest remaining entry: first in this row, then across the eight rows (ties: lowest row, lowest column)
+                double bm = -1.;
+                int brc = r << 4;
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const double v = fabs(A[j]);
+                    const bool take = !row_used && !((colmask >> j) & 1u) && v > bm;
+                    bm = take ? v : bm;
+                    brc = take ? ((r << 4) | j) : brc;
+                }
+#pragma unroll
+                for (int sft = 1; sft < 8; sft <<= 1) {
+                    const double om = __shfl_xor(bm, sft);
+                    const int orc = __shfl_xor(brc, sft);
+                    const bool take = om > bm || (om == bm && (orc >> 4) < (brc >> 4));
+                    bm = take ? om : bm;
+                    brc = take ? orc : brc;
+                }
+                if (!(bm >= 1e-12)) ok = false;   // same for the eight lanes; they run on (shuffles need all of them)
+                const int pr = brc >> 4, pc = brc & 15;
+                double P[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) P[j] = __shfl(A[j], gbase | pr);
+                const double inv = 1. / RO_PICK9(P, pc);
+                const double mult = RO_PICK9(A, pc) * inv;
+                colmask |= 1u << pc;
+                if (r == pr) {
+                    row_used = true;
+                    my_pc = pc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        if (!((colmask >> j) & 1u)) A[j] = A[j] - mult * P[j];
+                }
+            }
+            const int free_col = __builtin_ctz(~colmask & 0x1ffu);
+            const double y = -RO_PICK9(A, free_col) / RO_PICK9(A, my_pc);
+            Fs[hl][my_pc] = y;
+            if (r == 0) {
+                Fs[hl][free_col] = 1.;
+                valid[hl] = (ok && h < a.hypotheses) ? 1 : 0;
+            }
         }
-        const float4 m = mine < RO_NORM_LDS ? nl[mine] : a.norm[first + mine];
-        const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
-        double A[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.};
-        uint32_t colmask = 0;
-        bool row_used = false, ok = true;
-        int my_pc = 0;
-#pragma unroll
-        for (int step = 0; step < 8; step++) {
-            // largest remaining entry: first in this row, then across the eight rows (ties: lowest row, lowest column)
-            double bm = -1.;
-            int brc = r << 4;
-#pragma unroll
-            for (int j = 0; j < 9; j++) {
-                const double v = fabs(A[j]);
-                const bool take = !row_used && !((colmask >> j) & 1u) && v > bm;
-                bm = take ? v : bm;
-                brc = take ? ((r << 4) | j) : brc;
-            }
-#pragma unroll
-            for (int sft = 1; sft < 8; sft <<= 1) {
-                const double om = __shfl_xor(bm, sft);
-                const int orc = __shfl_xor(brc, sft);
-                const bool take = om > bm || (om == bm && (orc >> 4) < (brc >> 4));
-                bm = take ? om : bm;
-                brc = take ? orc : brc;
-            }
-            if (!(bm >= 1e-12)) ok = false;   // same for the eight lanes; they run on (shuffles need all of them)
-            const int pr = brc >> 4, pc = brc & 15;
-            double P[9];
-#pragma unroll
-            for (int j = 0; j < 9; j++) P[j] = __shfl(A[j], gbase | pr);
-            const double inv = 1. / RO_PICK9(P, pc);
-            const double mult = RO_PICK9(A, pc) * inv;
-            colmask |= 1u << pc;
-            if (r == pr) {
-                row_used = true;
-                my_pc = pc;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 9; j++)
-                    if (!((colmask >> j) & 1u)) A[j] = A[j] - mult * P[j];
-            }
-        }
-        const int free_col = __builtin_ctz(~colmask & 0x1ffu);
-        const double y = -RO_PICK9(A, free_col) / RO_PICK9(A, my_pc);
-        Fs[hl][my_pc] = y;
-        if (r == 0) {
-            Fs[hl][free_col] = 1.;
-            valid[hl] = (ok && h < a.hypotheses) ? 1 : 0;
-        }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- inlier counts: 32 models x 8 slices of the point set ----
-    {
-        const int hh = t & 31, slice = t >> 5;
-        if (valid[hh]) {
-            double F[9];
+        // ---- inlier counts: 32 models x 8 slices of the point set ----
+        {
+            const int hh = t & 31, slice = t >> 5;
+            if (valid[hh] && h0 + hh < s_stop) {
+                double F[9];
 #pragma unroll
-            for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
-            int c = 0;
-            for (int i = slice; i < n; i += 8) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
-            atomicAdd(&cnt[hh], c);
+                for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
+                int c = 0;
+                for (int i = slice; i < n; i += 8) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
+                atomicAdd(&cnt[hh], c);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- most inliers wins, the lower hypothesis index on ties; at least 8 inliers ----
-    if (t == 0) {
-        int bh = -1, bc = 7;
-        for (int q = 0; q < RO_HYP_PER_WG; q++)
-            if (valid[q] && cnt[q] > bc) { bc = cnt[q]; bh = q; }
-        out->count = bh < 0 ? -1 : bc;
-        out->hyp = h0 + (bh < 0 ? 0 : bh);
-        if (bh >= 0)
-            for (int q = 0; q < 9; q++) out->F[q] = Fs[bh][q];
+        // ---- the round's models in index order, as a sequential loop over hypotheses would see them ----
+        if (t == 0) {
+            int stop = s_stop, best = s_best;
+            for (int q = 0; q < RO_HYP_PER_WG && h0 + q < stop; q++) {
+                if (!valid[q] || cnt[q] <= best) continue;
+                best = cnt[q];
+                for (int k = 0; k < 9; k++) best_F[k] = Fs[q][k];
+                s_have = 1;
+                const int need = ro_hypotheses_needed(best, n, a.hypotheses);
+                stop = need < stop ? need : stop;
+            }
+            s_stop = stop; s_best = best;
+        }
+        __syncthreads();
     }
-}
 
-__global__ void __launch_bounds__(256) ransac_select_kernel(OutlierArgs a, const RansacPartial* __restrict__ part) {
-    __shared__ double best_F[9];
-    __shared__ int winner;
-    const int t = threadIdx.x;
-    const LKJobDev* job = a.jobs + blockIdx.x;
-    const int first = job->first, n = job->count;
-    const double* c0 = job->calib;
-    const double* c1 = job->calib + 8;
-    const double f0 = c0[0] < c0[1] ? c0[1] : c0[0], f1 = c1[0] < c1[1] ? c1[1] : c1[0];
-    const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
-    if (t == 0) {
-        const RansacPartial* p = part + (size_t)blockIdx.x * RO_WG_PER_JOB;
-        int bw = -1, bc = 7;
-        for (int q = 0; q < RO_WG_PER_JOB; q++)      // ascending hypothesis ranges: a strict test keeps the lower index
-            if (p[q].count > bc) { bc = p[q].count; bw = q; }
-        winner = bw;
-        if (bw >= 0)
-            for (int q = 0; q < 9; q++) best_F[q] = p[bw].F[q];
-    }
-    __syncthreads();
-    const bool have_model = winner >= 0;
+    // ---- final mask and the batch results into the pinned host block ----
+    const bool have_model = s_have != 0;
     for (int i = t; i < n; i += 256) {
         const int g = first + i;
-        const bool keep = have_model && a.status[g] && ro_inlier(best_F, a.norm[g], thr2);
+        const bool keep = have_model && a.status[g] && ro_inlier(best_F, i < RO_NORM_LDS ? nl[i] : a.norm[g], thr2);
         a.out_xy[2 * g] = a.next_xy[2 * g];
         a.out_xy[2 * g + 1] = a.next_xy[2 * g + 1];
         a.out_err[g] = a.err[g];

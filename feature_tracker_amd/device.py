@@ -61,7 +61,8 @@ class ft_keypoint(C.Structure):
 class ft_kernel_time(C.Structure):
     _fields_ = [("pyramid_ms", C.c_double), ("pyramid_launches", C.c_int), ("lk_ms", C.c_double), ("lk_launches", C.c_int),
                 ("fast_ms", C.c_double), ("fast_launches", C.c_int),
-                ("lk_points", C.c_longlong), ("lk_level_visits", C.c_longlong), ("lk_iterations", C.c_longlong)]
+                ("lk_points", C.c_longlong), ("lk_level_visits", C.c_longlong), ("lk_iterations", C.c_longlong),
+                ("reject_ms", C.c_double), ("reject_launches", C.c_int)]
 
 
 # every symbol include/ft_device.h declares
@@ -404,7 +405,8 @@ class DeviceContext:
         self._check(self.lib.ft_kernel_times(self._ctx, C.byref(t), int(reset)), "ft_kernel_times")
         return {"pyramid_ms": t.pyramid_ms, "pyramid_launches": t.pyramid_launches, "lk_ms": t.lk_ms,
                 "lk_launches": t.lk_launches, "fast_ms": t.fast_ms, "fast_launches": t.fast_launches,
-                "lk_points": t.lk_points, "lk_level_visits": t.lk_level_visits, "lk_iterations": t.lk_iterations}
+                "lk_points": t.lk_points, "lk_level_visits": t.lk_level_visits, "lk_iterations": t.lk_iterations,
+                "reject_ms": t.reject_ms, "reject_launches": t.reject_launches}
 
     def queue_time_begin(self):
         self._check(self.lib.ft_queue_time_begin(self._ctx), "ft_queue_time_begin")

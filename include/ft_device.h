@@ -48,6 +48,8 @@ extern "C" {
  * the tail of TrackKLT::perform_matching, src/track/TrackKLT.cpp:405-424 (undistort_point + cv::findFundamentalMat
  * (FM_RANSAC, 1/max_focal, 0.999) + mask_klt & mask_ransac).  Model, error measure and threshold are OpenCV's; the
  * sampling is this library's own seeded scheme, because OpenCV's random sequence cannot be reproduced without it.
+ * Hypotheses are tried in index order and, as in OpenCV, a better model lowers the number still to be tried (to the
+ * smallest N with (1 - w^8)^N <= 0.001 for its inlier ratio w: confidence 0.999); ransac_hypotheses is the upper bound.
  * Jobs need calib_prev / calib_next. */
 #define FT_LK_REJECT_OUTLIERS 512
 /* Do not compute the residual (err stays 0).  TrackKLT::perform_matching never reads the `error` vector it gets from
@@ -132,6 +134,7 @@ typedef struct ft_kernel_time {
     /* LK work done while ft_profile mode 2 is on: points tracked, (point, level) pairs whose template was evaluated,
      * and Newton iterations summed over them (from the kernel's own per-level counters) */
     long long lk_points, lk_level_visits, lk_iterations;
+    double reject_ms;    int reject_launches;     /* outlier rejection (FT_LK_REJECT_OUTLIERS, ft_reject_outliers) */
 } ft_kernel_time;
 
 int ft_ctx_create(ft_ctx** out, int device, const ft_limits* limits);

@@ -722,6 +722,24 @@ inline bool is_inlier(const double (&F)[9], float x1, float y1, float x2, float 
     return err <= thr2;
 }
 
+// Hypotheses to try before a sample of eight inliers has been drawn with probability 0.999 (the confidence handed to
+// cv::findFundamentalMat at src/track/TrackKLT.cpp:418), given the best model so far has `inliers` of n points: the
+// smallest N with (1 - w^8)^N <= 0.001, at most max_h.  OpenCV's RANSAC lowers its iteration count the same way
+// whenever it finds a better model; here the count comes from plain multiplications in a fixed order.
+int hypotheses_needed(int inliers, int n, int max_h) {
+    const double w = (double)inliers / (double)n;
+    const double w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
+    const double q = 1. - w8;
+    double p = 1.;
+    int N = 0;
+    while (N < max_h) {
+        p = p * q;
+        N++;
+        if (p <= 0.001) break;
+    }
+    return N;
+}
+
 }  // namespace
 
 extern "C" {
@@ -743,7 +761,8 @@ int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* sta
     const float thr = (float)(1. / fmax), thr2 = thr * thr;
     int best_h = -1, best_count = 7;   // a model needs at least 8 inliers
     double best_F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int h = 0; h < hypotheses; h++) {
+    int stop = hypotheses;   // lowered whenever a better model is found
+    for (int h = 0; h < stop; h++) {
         int idx[8];
         uint32_t draw = 0;
         for (int k = 0; k < 8; k++) {
@@ -766,7 +785,11 @@ int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* sta
         if (!null_vector_8x9(A, F)) continue;
         int count = 0;
         for (int i = 0; i < n; i++) count += is_inlier(F, m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3], thr2) ? 1 : 0;
-        if (count > best_count) { best_count = count; best_h = h; for (int q = 0; q < 9; q++) best_F[q] = F[q]; }
+        if (count > best_count) {
+            best_count = count; best_h = h;
+            for (int q = 0; q < 9; q++) best_F[q] = F[q];
+            stop = std::min(stop, hypotheses_needed(count, n, hypotheses));
+        }
     }
     if (best_h < 0) {
         for (int i = 0; i < n; i++) status[i] = 0;

@@ -106,8 +106,11 @@ void fto_homography(const float* K4, const float* R_p_c, float* H);
  * variant with the same model, error measure and threshold:
  *   - both point sets are undistorted like TrackBase::undistort_point (src/track/TrackBase.h:289-332) and rounded to
  *     float, calib8 = fx, fy, cx, cy, k1, k2, p1, p2;
- *   - `hypotheses` models (0 = 256) are fitted, model h from the 8 distinct pairs drawn by a counter-based hash of
- *     (seed, h, draw number); the null vector of the 8x9 epipolar system comes from Gauss-Jordan elimination with complete
+ *   - at most `hypotheses` models (0 = 256) are fitted in index order, model h from the 8 distinct pairs drawn by a
+ *     counter-based hash of (seed, h, draw number).  Whenever a model beats the best so far, the number of models still
+ *     to be tried drops to the smallest N with (1 - w^8)^N <= 0.001, w = that model's inlier ratio: the adaptive
+ *     iteration count behind the confidence argument 0.999 (OpenCV computes it with logarithms; here it comes from
+ *     repeated multiplication in a fixed order, so that every implementation gets the same N).  The null vector of the 8x9 epipolar system comes from Gauss-Jordan elimination with complete
  *     pivoting in double precision (ties: lowest row, then lowest column; a sample whose pivot falls below 1e-12 is skipped);
  *   - a pair is an inlier of a model if (float)max(d1^2*s1, d2^2*s2) <= thr^2, the symmetric epipolar distance of
  *     OpenCV's estimator, thr = 1 / max(fx, fy of both cameras);
