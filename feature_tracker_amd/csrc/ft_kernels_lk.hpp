@@ -170,6 +170,15 @@ __device__ __forceinline__ BilinW bilin_weights(float a, float b) {
 __device__ __forceinline__ int dot2_acc(uint32_t pair, uint32_t wpair, int acc) {
     return __builtin_amdgcn_sdot2(v2s(pair), v2s(wpair), acc, false);
 }
+// The same product with the sum going to a new register (three-operand form).  The builtin above becomes the
+// accumulate-in-place form, which costs a register copy whenever the addend has to survive, as the template terms kept
+// for all iterations of a level do.  Not to be used for a value that a DPP instruction reads next (the compiler
+// cannot see through the assembly to place the wait states that needs).
+__device__ __forceinline__ int dot2_to(uint32_t pair, uint32_t wpair, int addend) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(pair), "v"(wpair), "v"(addend));
+    return r;
+}
 // upper 16-bit field of lo followed by the lower field of hi: the pair one element further along
 __device__ __forceinline__ uint32_t next_pair(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 // low halves of two ints as one 16-bit pair
@@ -190,6 +199,7 @@ __device__ __forceinline__ int reflect101_once(int p, int len) {
 }
 
 struct __attribute__((packed)) LkU32Unaligned { uint32_t v; };
+struct __attribute__((packed, aligned(4))) LkU64Unaligned { uint32_t a, b; };
 
 // load image columns [x_first, x_last] x rows [y_first, y_first + n_rows) into LDS (REFLECT_101 outside the image).
 // Lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...; the LDS array holds 4*MAXR rows.
@@ -208,18 +218,24 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
     // wave-uniform cases, cheapest first
     const bool interior = R.rx0 >= 0 && R.rx0 + 4 * LK_RW_DWORDS <= w && R.ry0 >= 0 && R.ry0 + R.rh <= h;
     if (interior) {
-        // every staged byte is an image byte: no border arithmetic.  Rows past the region (never read) are clamped
-        // into the image so that all 4*MAXR rows can be loaded and stored without per-row predicates.
-        if (c < LK_RW_DWORDS) {
-            uint32_t v[MAXR];
+        // every staged byte is an image byte: no border arithmetic.  Here a lane owns a pair of dwords, lane (c2, r8) =
+        // (lane & 7, lane >> 3) the dwords 2*c2, 2*c2+1 of rows r8, r8+8, ...: half as many loads, LDS stores and
+        // address computations as with one dword per lane.  Rows past the region (never read) are clamped into the
+        // image so that all rows can be loaded without per-row predicates.
+        constexpr int MAXR8 = (4 * MAXR + 7) / 8;
+        const int c2 = lane & 7, r8 = lane >> 3;
+        if (2 * c2 < LK_RW_DWORDS) {
+            uint32_t va[MAXR8], vb[MAXR8];
 #pragma unroll
-            for (int k = 0; k < MAXR; k++) {
-                const int sy = min(R.ry0 + rr + 4 * k, h - 1);
-                v[k] = *reinterpret_cast<const uint32_t*>(img + (__umul24(sy, pitch) + (uint32_t)gx));   // uniform base + 32-bit offset
+            for (int k = 0; k < MAXR8; k++) {
+                const int sy = min(R.ry0 + r8 + 8 * k, h - 1);
+                const LkU64Unaligned q = *reinterpret_cast<const LkU64Unaligned*>(img + (__umul24(sy, pitch) + (uint32_t)(R.rx0 + 8 * c2)));   // uniform base + 32-bit offset
+                va[k] = q.a; vb[k] = q.b;
             }
-            uint32_t* dst = lds + rr * LK_PITCH + c;
+            uint32_t* dst = lds + r8 * LK_PITCH + 2 * c2;
 #pragma unroll
-            for (int k = 0; k < MAXR; k++) dst[4 * k * LK_PITCH] = v[k];
+            for (int k = 0; k < MAXR8; k++)
+                if ((4 * MAXR) % 8 == 0 || r8 + 8 * k < 4 * MAXR) { dst[8 * k * LK_PITCH] = va[k]; dst[8 * k * LK_PITCH + 1] = vb[k]; }
         }
         return R;
     }
@@ -411,6 +427,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     int st = 1;
     float errv = 0.f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps_f = (float)a.epsilon, eps_band = eps_f * 1e-4f + 1e-30f;
 
     for (int level = a.max_level; level >= 0; level--) {
         int w = job->w0, h = job->h0;
@@ -471,12 +488,14 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
             const int gy = ipy + rc;
             // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
+            // (the column passes through an opaque assembly statement inside the border branch: otherwise the compiler
+            // hoists the border masks' comparisons above the branch and every window pays for them)
             if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
-            else scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, ipx + x0 - 1, w);
+            else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, col0, w); }
             __builtin_amdgcn_sched_barrier(0);
             read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 3, boff, Rd);
             if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
-            else scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, ipx + x0 - 1, w);
+            else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, col0, w); }
             __builtin_amdgcn_sched_barrier(0);
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
@@ -492,7 +511,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 // sample k blends pixel columns c = k+1, k+2 of region rows rc+1, rc+2
                 const uint32_t pb = (k & 1) ? Rb[(k + 1) / 2] : next_pair(Rb[k / 2 + 1], Rb[k / 2]);
                 const uint32_t pc = (k & 1) ? Rc[(k + 1) / 2] : next_pair(Rc[k / 2 + 1], Rc[k / 2]);
-                const int iw = dot2_acc(pc, wbot, dot2_acc(pb, wtop, 256)) >> 9;
+                const int iw = dot2_acc(pc, wbot, dot2_to(pb, wtop, 256)) >> 9;
                 Cw[k] = 256 - (iw << 9);
             }
             wave_sum_exact3(a11, a22, a12, A11, A22, A12);
@@ -531,8 +550,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int m = 0; m < SEGLEN / 2; m++) {
-                const int d0 = dot2_acc(p1[2 * m], wbot, dot2_acc(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
-                const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_acc(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
+                const int d0 = dot2_acc(p1[2 * m], wbot, dot2_to(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
+                const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_to(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
                 const uint32_t dp = pack_lo16(d1, d0);
                 b1 = dot2_acc(dp, GX[m], b1);
                 b2 = dot2_acc(dp, GY[m], b2);
@@ -544,7 +563,14 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nx += dx; ny += dy;
             outx = nx + half_x; outy = ny + half_y;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
+            // delta . delta <= epsilon in double precision, as the reference computes it.  The float value decides
+            // whenever it is clear of the bound by far more than its rounding error (a few 1e-7 relative); the double
+            // arithmetic, at half the issue rate, runs only in the band around the bound.  Uniform for the wave.
+            {
+                const float s = dx * dx + dy * dy;
+                const bool far = fabsf(s - eps_f) > eps_band;
+                if (far ? s < eps_f : (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
+            }
             // |dx + pdx| < 0.01 and |dy + pdy| < 0.01 in double precision: for a float, "< 0.01" is "< the float above 0.01"
             if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
@@ -574,7 +600,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 int e = 0;
 #pragma unroll
                 for (int k = 0; k < SEGLEN; k++) {
-                    const int diff = dot2_acc(p1[k], wbot, dot2_acc(p0[k], wtop, Cw[k])) >> 9;
+                    const int diff = dot2_acc(p1[k], wbot, dot2_to(p0[k], wtop, Cw[k])) >> 9;
                     if (k < n_valid) e += abs(diff);
                 }
                 const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact

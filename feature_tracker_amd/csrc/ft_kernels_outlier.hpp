@@ -77,6 +77,7 @@ __device__ __forceinline__ bool ro_inlier(const double* F, float4 m, float thr2)
 }
 
 constexpr int RO_HYP_PER_WG = 32;     // hypotheses per round (8 lanes each)
+constexpr int RO_SUB = 4;             // models whose inliers are counted together (a power of two)
 constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest is read from the global copy
 
 // Hypotheses to try before a sample of eight inliers has been drawn with probability 0.999, given the best model so far
@@ -210,34 +211,36 @@ __global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
         }
         __syncthreads();
 
-        // ---- inlier counts: 32 models x 8 slices of the point set ----
-        {
-            const int hh = t & 31, slice = t >> 5;
-            if (valid[hh] && h0 + hh < s_stop) {
-                double F[9];
+        // ---- inlier counts and the walk over the models in index order, RO_SUB models at a time: the search usually
+        //      ends within the first few hypotheses, and the models past that point are never counted ----
+        for (int q0 = 0; q0 < RO_HYP_PER_WG && h0 + q0 < s_stop; q0 += RO_SUB) {   // s_stop: see above
+            {
+                const int hh = q0 + (t & (RO_SUB - 1)), slice = t / RO_SUB;
+                if (valid[hh] && h0 + hh < s_stop) {
+                    double F[9];
 #pragma unroll
-                for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
-                int c = 0;
-                for (int i = slice; i < n; i += 8) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
-                atomicAdd(&cnt[hh], c);
+                    for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
+                    int c = 0;
+                    for (int i = slice; i < n; i += 256 / RO_SUB) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
+                    if (c) atomicAdd(&cnt[hh], c);
+                }
             }
-        }
-        __syncthreads();
-
-        // ---- the round's models in index order, as a sequential loop over hypotheses would see them ----
-        if (t == 0) {
-            int stop = s_stop, best = s_best;
-            for (int q = 0; q < RO_HYP_PER_WG && h0 + q < stop; q++) {
-                if (!valid[q] || cnt[q] <= best) continue;
-                best = cnt[q];
-                for (int k = 0; k < 9; k++) best_F[k] = Fs[q][k];
-                s_have = 1;
-                const int need = ro_hypotheses_needed(best, n, a.hypotheses);
-                stop = need < stop ? need : stop;
+            __syncthreads();
+            // as a sequential loop over hypotheses would see them
+            if (t == 0) {
+                int stop = s_stop, best = s_best;
+                for (int q = q0; q < q0 + RO_SUB && h0 + q < stop; q++) {
+                    if (!valid[q] || cnt[q] <= best) continue;
+                    best = cnt[q];
+                    for (int k = 0; k < 9; k++) best_F[k] = Fs[q][k];
+                    s_have = 1;
+                    const int need = ro_hypotheses_needed(best, n, a.hypotheses);
+                    stop = need < stop ? need : stop;
+                }
+                s_stop = stop; s_best = best;
             }
-            s_stop = stop; s_best = best;
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- final mask and the batch results into the pinned host block ----

@@ -24,6 +24,8 @@ def run(label, **kw):
     ctx.profile(False)
     print(f"{label:28s} {1e3 * t['lk_ms'] / t['lk_launches']:8.1f} us  ({npts} points)", flush=True)
 run("full win21 L3")
+if len(sys.argv) > 1 and sys.argv[1] == "full":   # only the product configuration (for counter passes)
+    sys.exit(0)
 run("max_iter=1", max_iter=1)
 run("max_iter=0", max_iter=0)
 run("max_level=0", max_level=0)
