@@ -242,6 +242,13 @@ void lk_point_level(const LKCtx& c, int level, int i, std::vector<int16_t>& Ibuf
 
     const size_t stepI = I.stride, stepJ = J.stride, dstep = dI.stride;
     int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+    // FTO_LK_FLOAT_SUMS: float accumulators in the order of OpenCV's SSE2 code path (x86, acctype = float): four lanes
+    // across x take the pixels x = 0..4*floor(ww/4)-1 (lane = x mod 4), a scalar accumulator takes the rest of every
+    // row, and after the last row the four lanes are added to the scalar one, lane 0 first.  Every single product is
+    // an integer below 2^24, so only the additions round.
+    const bool fsum = (c.flags & FTO_LK_FLOAT_SUMS) != 0;
+    const int ww4 = ww - ww % 4;
+    float qA11[4] = {0, 0, 0, 0}, qA12[4] = {0, 0, 0, 0}, qA22[4] = {0, 0, 0, 0}, tA11 = 0.f, tA12 = 0.f, tA22 = 0.f;
     for (int y = 0; y < wh; y++) {
         const uint8_t* src = I.origin() + (ptrdiff_t)(y + ipy) * (ptrdiff_t)stepI + ipx;
         const int16_t* dsrc = dI.origin() + (ptrdiff_t)(y + ipy) * (ptrdiff_t)dstep + 2 * (ptrdiff_t)ipx;
@@ -257,11 +264,22 @@ void lk_point_level(const LKCtx& c, int level, int i, std::vector<int16_t>& Ibuf
             sA11 += (int64_t)ixval * ixval;
             sA12 += (int64_t)ixval * iyval;
             sA22 += (int64_t)iyval * iyval;
+            if (fsum) {
+                const float fx = (float)ixval, fy = (float)iyval;
+                if (x < ww4) { qA11[x & 3] += fx * fx; qA12[x & 3] += fx * fy; qA22[x & 3] += fy * fy; }
+                else { tA11 += (float)(ixval * ixval); tA12 += (float)(ixval * iyval); tA22 += (float)(iyval * iyval); }
+            }
         }
     }
     float A11 = (float)(double)sA11 * FLT_SCALE;
     float A12 = (float)(double)sA12 * FLT_SCALE;
     float A22 = (float)(double)sA22 * FLT_SCALE;
+    if (fsum) {
+        tA11 += qA11[0] + qA11[1] + qA11[2] + qA11[3];
+        tA12 += qA12[0] + qA12[1] + qA12[2] + qA12[3];
+        tA22 += qA22[0] + qA22[1] + qA22[2] + qA22[3];
+        A11 = tA11 * FLT_SCALE; A12 = tA12 * FLT_SCALE; A22 = tA22 * FLT_SCALE;
+    }
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
     if ((c.flags & FTO_LK_GET_MIN_EIGENVALS) && level == 0) c.err[i] = minEig;
@@ -286,18 +304,46 @@ void lk_point_level(const LKCtx& c, int level, int i, std::vector<int16_t>& Ibuf
         iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t sb1 = 0, sb2 = 0;
+        // FTO_LK_FLOAT_SUMS: OpenCV's SSE2 path takes eight pixels at a time; pixels k and k+4 of a group are
+        // multiplied and added as integers (pmaddwd), the pair sum is converted to float and added to one of four float
+        // lanes per component (k = 0, 1 -> first register, k = 2, 3 -> second register); the rest of the row goes to a
+        // scalar float accumulator; at the end the two registers are added and their lanes folded into the scalars.
+        const int ww8 = ww - ww % 8;
+        float qb1[4] = {0, 0, 0, 0}, qb2[4] = {0, 0, 0, 0}, tb1 = 0.f, tb2 = 0.f;
         for (int y = 0; y < wh; y++) {
             const uint8_t* Jp = J.origin() + (ptrdiff_t)(y + iny) * (ptrdiff_t)stepJ + inx;
             const int16_t* Ip = Ibuf.data() + (size_t)y * ww;
             const int16_t* dIp = dIbuf.data() + (size_t)y * ww * 2;
+            int dgrp[8];
             for (int x = 0; x < ww; x++) {
                 int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
                 sb1 += (int64_t)diff * dIp[2 * x];
                 sb2 += (int64_t)diff * dIp[2 * x + 1];
+                if (fsum) {
+                    if (x < ww8) {
+                        dgrp[x & 7] = diff;
+                        if ((x & 7) == 7) {
+                            const int16_t* g = dIp + 2 * (x - 7);
+                            for (int k = 0; k < 4; k++) {
+                                qb1[k] += (float)(dgrp[k] * g[2 * k] + dgrp[k + 4] * g[2 * (k + 4)]);
+                                qb2[k] += (float)(dgrp[k] * g[2 * k + 1] + dgrp[k + 4] * g[2 * (k + 4) + 1]);
+                            }
+                        }
+                    } else {
+                        tb1 += (float)(diff * dIp[2 * x]);
+                        tb2 += (float)(diff * dIp[2 * x + 1]);
+                    }
+                }
             }
         }
         float b1 = (float)(double)sb1 * FLT_SCALE;
         float b2 = (float)(double)sb2 * FLT_SCALE;
+        if (fsum) {
+            // registers: {b1(k=0), b2(k=0), b1(k=1), b2(k=1)} + {b1(k=2), b2(k=2), b1(k=3), b2(k=3)}, then lanes 0+2 and 1+3
+            tb1 += (qb1[0] + qb1[2]) + (qb1[1] + qb1[3]);
+            tb2 += (qb2[0] + qb2[2]) + (qb2[1] + qb2[3]);
+            b1 = tb1 * FLT_SCALE; b2 = tb2 * FLT_SCALE;
+        }
         float dx = (A12 * b2 - A22 * b1) * D;
         float dy = (A12 * b1 - A11 * b2) * D;
         nx += dx; ny += dy;

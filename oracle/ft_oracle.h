@@ -26,6 +26,8 @@ extern "C" {
 #define FTO_LK_GET_MIN_EIGENVALS 8
 #define FTO_LK_NO_ERROR 1024        /* leave err at 0 (the bounds test of the final position still applies to status) */
 #define FTO_LK_FORWARD_BACKWARD 256 /* build-defined: see fto_lk_track */
+#define FTO_LK_FLOAT_SUMS 2048       /* test switch: accumulate the normal-equation sums in float, in the order of OpenCV's SSE2
+                                       code path, instead of exactly (bounds the one deliberate deviation of fto_lk_track) */
 #define FTO_LK_REJECT_OUTLIERS 512  /* build-defined: see fto_reject_outliers (applied by the tracker backend) */
 
 typedef struct fto_pyramid fto_pyramid;

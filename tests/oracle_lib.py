@@ -13,6 +13,7 @@ LK_USE_INITIAL_FLOW = 4
 LK_GET_MIN_EIGENVALS = 8
 LK_FORWARD_BACKWARD = 256
 LK_REJECT_OUTLIERS = 512
+LK_FLOAT_SUMS = 2048
 
 
 class fto_lk_params(C.Structure):
