@@ -1,0 +1,181 @@
+"""TrackKLT::feed_stereo restated in Python from the reference's source (src/track/TrackKLT.cpp:27-219 feed_stereo,
+:223-368 perform_detection_stereo, :371-432 perform_matching), driven by kernel-level calls of the CPU oracle.
+
+Test infrastructure.  The product's orchestration (feature_tracker_amd/src/track/TrackKLT.cpp) is compared with this
+restatement frame by frame, so a slip in the product's control flow (occupancy rules, "need > 1", id assignment, the
+stereo / left-only / right-only merge, the reset rule) cannot hide behind the fact that the GPU run and the CPU checker
+run share that source file.  Deliberately simple: lists and loops in the reference's order, no batching, no caches.
+
+What is not the reference's but this build's own definition, on both sides: the seeded RANSAC behind
+cv::findFundamentalMat (seed = number of stereo pairs fed so far), and points whose occupancy cell lies outside the
+grid are dropped (the reference indexes its Eigen matrix out of bounds there).
+"""
+import numpy as np
+
+import oracle_lib as O
+
+LK_NO_ERROR = 1024
+
+
+def undistort_point(pt, calib8):
+    """TrackBase::undistort_point (src/track/TrackBase.h:289-332): cv::undistortPoints for one point, float result."""
+    fx, fy, cx, cy, k1, k2, p1, p2 = [float(v) for v in calib8]
+    x0, y0 = (float(pt[0]) - cx) * (1.0 / fx), (float(pt[1]) - cy) * (1.0 / fy)
+    x, y = x0, y0
+    if k1 != 0 or k2 != 0 or p1 != 0 or p2 != 0:
+        for _ in range(5):
+            r2 = x * x + y * y
+            icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2)
+            dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+            dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+            x, y = (x0 - dx) * icdist, (y0 - dy) * icdist
+    return np.float32(x), np.float32(y)
+
+
+class Occupancy:
+    """grid_2d of perform_detection_stereo (:230-231): (rows/min_px_dist + 2) x (cols/min_px_dist + 2) cells, indexed by
+    (int)(coordinate / min_px_dist) with the division in float."""
+
+    def __init__(self, cols, rows, dist):
+        self.gw, self.gh, self.dist = cols // dist + 2, rows // dist + 2, dist
+        self.cell = np.zeros((self.gh, self.gw), dtype=bool)
+
+    def index(self, pt):
+        cx, cy = int(np.float32(pt[0]) / np.float32(self.dist)), int(np.float32(pt[1]) / np.float32(self.dist))
+        if cx < 0 or cy < 0 or cx >= self.gw or cy >= self.gh:
+            return None
+        return cy, cx
+
+    def taken(self, pt):
+        i = self.index(pt)
+        return True if i is None else bool(self.cell[i])
+
+    def take(self, pt):
+        i = self.index(pt)
+        if i is not None:
+            self.cell[i] = True
+
+
+class StereoTrackerRef:
+    def __init__(self, num_features=150, fast_threshold=20, grid_x=5, grid_y=5, min_px_dist=10, win=15, levels=3, calib=None,
+                 hypotheses=256, reject_outliers=True):
+        self.num_features, self.threshold, self.grid_x, self.grid_y, self.min_px_dist = num_features, fast_threshold, grid_x, grid_y, min_px_dist
+        self.win, self.levels, self.calib, self.hypotheses, self.reject = win, levels, calib, hypotheses, reject_outliers
+        self.currid = 1                       # TrackBase(numfeats, numaruco = 0): currid = numaruco + 1 (src/track/TrackBase.h:86-89)
+        self.pts = {0: [], 1: []}             # pts_last: lists of (x, y) float32
+        self.ids = {0: [], 1: []}
+        self.pyr_last = {0: None, 1: None}
+        self.size = None
+        self.pairs_fed = 0
+        self.database = {}                    # id -> cam -> list of (t, u, v, un, vn)
+
+    # ---- :223-368 ----
+    def perform_detection_stereo(self, img0, img1, pts0, pts1, ids0, ids1, pyr0, pyr1):
+        rows, cols = img0.shape
+        grid0, grid1 = Occupancy(cols, rows, self.min_px_dist), Occupancy(img1.shape[1], img1.shape[0], self.min_px_dist)
+        for grid, pts, ids in ((grid0, pts0, ids0), (grid1, pts1, ids1)):
+            i = 0
+            while i < len(pts):                                   # :232-263, first come wins
+                if grid.taken(pts[i]):
+                    del pts[i], ids[i]
+                    continue
+                grid.take(pts[i])
+                i += 1
+        need0 = self.num_features - len(pts0)
+        if need0 > 1:                                             # :271
+            ext = O.grid_fast(img0, need0, self.grid_x, self.grid_y, self.threshold)          # :275
+            new = []
+            for x, y, _ in ext:                                   # :280-288
+                if grid0.taken((x, y)):
+                    continue
+                new.append((np.float32(x), np.float32(y)))
+                grid0.take((x, y))
+            if new:
+                p0 = np.array(new, dtype=np.float32).reshape(-1, 2)
+                # same-pixel initial guess, plain LK without the rejection step (:290-306)
+                p1, mask, _ = O.lk_track(pyr0, pyr1, p0, guess=p0.copy(), win=self.win, max_level=self.levels,
+                                         flags=O.LK_USE_INITIAL_FLOW | LK_NO_ERROR)
+                for i in range(len(p0)):                          # :309-338
+                    a, b = p0[i], p1[i]
+                    oob0 = a[0] < 0 or a[1] < 0 or a[0] >= cols or a[1] >= rows
+                    oob1 = b[0] < 0 or b[1] < 0 or b[0] >= img1.shape[1] or b[1] >= img1.shape[0]
+                    if not oob0 and mask[i] == 1 and not oob1 and not grid1.taken(b):
+                        self.currid += 1
+                        pts0.append((a[0], a[1])); pts1.append((b[0], b[1]))
+                        ids0.append(self.currid); ids1.append(self.currid)
+                    elif not oob0:
+                        self.currid += 1
+                        pts0.append((a[0], a[1]))
+                        ids0.append(self.currid)
+        need1 = self.num_features - len(pts1)
+        if need1 > 1:                                             # :346
+            ext = O.grid_fast(img1, need1, self.grid_x, self.grid_y, self.threshold)          # :350
+            for x, y, _ in ext:                                   # :353-362
+                if grid1.taken((x, y)):
+                    continue
+                pts1.append((np.float32(x), np.float32(y)))
+                self.currid += 1
+                ids1.append(self.currid)
+                grid1.take((x, y))
+
+    # ---- :371-432 ----
+    def perform_matching(self, pyr0, pyr1, kpts0, cam0, cam1):
+        """Returns (mask or None, new positions)."""
+        if not kpts0:
+            return None, []                                       # :377-381, mask stays empty
+        p0 = np.array(kpts0, dtype=np.float32).reshape(-1, 2)
+        if len(p0) < 10:                                          # :392-396
+            return np.zeros(len(p0), dtype=np.uint8), [tuple(p) for p in p0]
+        p1, mask, _ = O.lk_track(pyr0, pyr1, p0, guess=p0.copy(), win=self.win, max_level=self.levels,
+                                 flags=O.LK_USE_INITIAL_FLOW | LK_NO_ERROR)                    # :402
+        if self.reject:                                           # :405-424: mask_klt && mask_rsc
+            mask = O.reject_outliers(p0, p1, mask, self.calib[cam0], self.calib[cam1], hypotheses=self.hypotheses, seed=self.pairs_fed)[0]
+        return mask, [(p[0], p[1]) for p in p1]
+
+    # ---- :27-219 ----
+    def feed_stereo(self, t, left, right):
+        pyrL, pyrR = O.Pyramid(left, self.win, self.levels), O.Pyramid(right, self.win, self.levels)    # :45-58
+        self.pairs_fed += 1
+        ptsL, ptsR, idsL, idsR = self.pts[0], self.pts[1], self.ids[0], self.ids[1]
+        if not ptsL or not ptsR:                                  # :62-72
+            self.perform_detection_stereo(left, right, ptsL, ptsR, idsL, idsR, pyrL, pyrR)
+            self._roll(left, right, pyrL, pyrR)
+            return
+        lastL, lastR = self.img_last
+        self.perform_detection_stereo(lastL, lastR, ptsL, ptsR, idsL, idsR, self.pyr_last[0], self.pyr_last[1])   # :76-78
+        mask_ll, newL = self.perform_matching(self.pyr_last[0], pyrL, ptsL, 0, 0)                                 # :91-98
+        mask_rr, newR = self.perform_matching(self.pyr_last[1], pyrR, ptsR, 1, 1)
+        if mask_ll is None or mask_rr is None:                    # :118-129
+            self._roll(left, right, pyrL, pyrR)
+            self.pts, self.ids = {0: [], 1: []}, {0: [], 1: []}
+            return
+        good_l, good_r, gid_l, gid_r = [], [], [], []
+        for i, p in enumerate(newL):                              # :136-166
+            if p[0] < 0 or p[1] < 0:
+                continue
+            index_right = idsR.index(idsL[i]) if idsL[i] in idsR else None
+            if mask_ll[i] and index_right is not None and mask_rr[index_right]:
+                q = newR[index_right]
+                if q[0] < 0 or q[1] < 0:
+                    continue
+                good_l.append(p); good_r.append(q); gid_l.append(idsL[i]); gid_r.append(idsR[index_right])
+            elif mask_ll[i]:
+                good_l.append(p); gid_l.append(idsL[i])
+        for i, q in enumerate(newR):                              # :169-181
+            if q[0] < 0 or q[1] < 0:
+                continue
+            if mask_rr[i] and idsR[i] not in gid_r:
+                good_r.append(q); gid_r.append(idsR[i])
+        for cam, good, gids in ((0, good_l, gid_l), (1, good_r, gid_r)):     # :187-198
+            for p, fid in zip(good, gids):
+                un, vn = undistort_point(p, self.calib[cam])
+                self.database.setdefault(fid, {}).setdefault(cam, []).append((t, p[0], p[1], un, vn))
+        self._roll(left, right, pyrL, pyrR)                       # :201-208
+        self.pts, self.ids = {0: good_l, 1: good_r}, {0: gid_l, 1: gid_r}
+
+    def _roll(self, left, right, pyrL, pyrR):
+        self.img_last = (left, right)
+        self.pyr_last = {0: pyrL, 1: pyrR}
+
+    def points(self, cam):
+        return np.array(self.pts[cam], dtype=np.float32).reshape(-1, 2), np.array(self.ids[cam], dtype=np.uint64)
