@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -124,6 +125,7 @@ struct ft_ctx {
     hipEvent_t region_a = nullptr, region_b = nullptr;
 
     std::string hip_err;
+    std::mutex err_mutex;   // ft_stage_frame may fail on several threads at once
 };
 
 namespace {
@@ -132,6 +134,7 @@ namespace {
     do {                                                                                           \
         hipError_t e__ = (call);                                                                   \
         if (e__ != hipSuccess) {                                                                   \
+            std::lock_guard<std::mutex> lk__((ctx)->err_mutex);                                    \
             (ctx)->hip_err = std::string(#call) + ": " + hipGetErrorString(e__);                   \
             return FT_E_HIP;                                                                       \
         }                                                                                          \

@@ -33,7 +33,10 @@ public:
     }
 
     ~TrackKLTBatch() {
-        if (late_pending) (void)be->wait(det_token);   // the backend still holds pointers into det[] for that delivery
+        // Undelivered asynchronous results (a set between begin() and complete(), a staged lookahead set, a late
+        // detector) leave the backend holding pointers into plans[], det[] and last_buf: let it deliver them while
+        // those arrays still exist.
+        if (pending || staged || late_pending) (void)be->sync();
     }
 
     static int default_host_threads(int n_streams) {
