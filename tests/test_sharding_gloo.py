@@ -66,3 +66,41 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert tracked == ranks[0]["tracked_all"] and attempted == ranks[0]["attempted_all"]
     merged = dict(ranks[0]["per_stream"], **ranks[1]["per_stream"])
     assert merged == {k: list(v) for k, v in per_stream.items()}
+
+
+def test_bench_stream_assignment_for_both_scaling_modes():
+    """bench.py's own assignment: strong scaling deals the workload's streams round-robin (a partition of the global
+    ids, stream s on rank s mod N); weak scaling and per-GPU workloads give every rank the full count with ids that no
+    other rank uses."""
+    sys.path.insert(0, ROOT)
+    import bench
+    wl = bench.WORKLOADS["cfg4"]
+    for world in (1, 2, 4, 8):
+        strong = [bench.stream_ids_of_rank(wl, "strong", r, world) for r in range(world)]
+        assert sorted(i for ids in strong for i in ids) == list(range(wl["streams"]))
+        assert all(i % world == r for r, ids in enumerate(strong) for i in ids)
+        weak = [bench.stream_ids_of_rank(wl, "weak", r, world) for r in range(world)]
+        assert all(len(ids) == wl["streams"] for ids in weak)
+        flat = [i for ids in weak for i in ids]
+        assert len(set(flat)) == len(flat)
+    per_gpu = bench.WORKLOADS["cfg5"]
+    assert per_gpu.get("per_gpu") and all(len(bench.stream_ids_of_rank(per_gpu, "strong", r, 8)) == per_gpu["streams"] for r in range(8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_on_one_gpu(scaling, tmp_path):
+    """bench.py itself with two ranks (gloo for the reduction of the totals, both ranks on GPU 0): the JSON line names the
+    scaling mode and the total stream count, and the job's rate is the sum over ranks divided by the slowest rank's time."""
+    env = dict(os.environ, FT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "1",
+           "--workload", "cfg2" if scaling == "weak" else "cfg4", "--scaling", scaling]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 6 and out["warmup"] == 2
+    want_total = 64 if scaling == "strong" else 2
+    assert out["config"]["streams_total"] == want_total and out["config"]["streams_this_gpu"] == want_total // 2
+    assert out["value"] > 0 and abs(out["frames_per_sec"] - want_total * 6 / (out["ms_per_step"] * 6e-3)) < 1e-6 * out["frames_per_sec"]

@@ -6,7 +6,7 @@ tag=${1:-r1}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 40 --warmup 8 --no-cpu-baseline --no-latency"
+args="--steps 40 --warmup 8 --repeats 1 --no-extra-legs --no-cpu-baseline --no-latency"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py $args > $out/trace_bench.json 2> $out/trace.err
 echo trace done
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o bench -- python3 bench.py $args > $out/pmc_fetch_bench.json 2> $out/pmc_fetch.err

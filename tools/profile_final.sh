@@ -6,7 +6,7 @@ tag=${1:-r1_h}
 bash tools/profile_bench.sh $tag
 out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_g1 -o bench -- python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-latency --groups 1 > $out/trace_g1_bench.json 2> $out/trace_g1.err
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_g1 -o bench -- python3 bench.py --steps 40 --warmup 8 --repeats 1 --no-extra-legs --no-cpu-baseline --no-latency --groups 1 > $out/trace_g1_bench.json 2> $out/trace_g1.err
 find $out/trace_g1 -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_groups1.csv \;
 echo groups1 done
 bash tools/pmc_bench_insts.sh
