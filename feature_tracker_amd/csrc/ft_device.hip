@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ft_common.hpp"
+#include "ft_kernels_brief.hpp"
 #include "ft_kernels_fast.hpp"
 #include "ft_kernels_lk.hpp"
 #include "ft_kernels_match.hpp"
@@ -959,26 +960,53 @@ void ft_homography(const float* K4, const float* R, float* H) {
     }
 }
 
+// descriptor staging (device + pinned host, 80 bytes per descriptor of capacity), grown on demand
+static int ensure_match_cap(ft_ctx* c, size_t need) {
+    if (need <= c->match_cap) return FT_OK;
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    if (c->match_dev) (void)hipFree(c->match_dev);
+    if (c->match_host) (void)hipHostFree(c->match_host);
+    c->match_dev = nullptr; c->match_host = nullptr; c->match_cap = 0;
+    const size_t cap_n = align_up(need, 1024);
+    void* p = nullptr;
+    FT_HIP(c, hipMalloc(&p, cap_n * (32 + 8) * 2));
+    c->match_dev = (uint8_t*)p;
+    FT_HIP(c, hipHostMalloc(&p, cap_n * (32 + 8) * 2, hipHostMallocDefault));
+    c->match_host = (uint8_t*)p;
+    c->match_cap = cap_n;
+    return FT_OK;
+}
+
+int ft_compute_descriptors(ft_ctx* c, int stream, int slot, const float* xy, int n, uint8_t* desc, uint8_t* valid) {
+    if (!c || n < 0 || (n > 0 && (!xy || !desc || !valid))) return FT_E_INVALID;
+    const int si = slot_index(c, stream, slot);
+    if (si < 0) return FT_E_INVALID;
+    if (c->slots[si].levels < 1) return FT_E_STATE;
+    if (n > 65536) return FT_E_LIMIT;
+    if (n == 0) return FT_OK;
+    FT_HIP(c, hipSetDevice(c->device));
+    { const int rc = ensure_match_cap(c, (size_t)n); if (rc) return rc; }
+    // layout of both blocks: positions (8 n), descriptors (32 n), valid flags (n)
+    const size_t off_desc = align_up(8 * (size_t)n, 256), off_valid = off_desc + 32 * (size_t)n;
+    memcpy(c->match_host, xy, 8 * (size_t)n);
+    FT_HIP(c, hipMemcpyAsync(c->match_dev, c->match_host, 8 * (size_t)n, hipMemcpyHostToDevice, c->q));
+    hipLaunchKernelGGL(brief_kernel, dim3(n), dim3(64), 0, c->q, c->arena, si, c->slots[si].w, c->slots[si].h,
+                       reinterpret_cast<const float*>(c->match_dev), n, c->match_dev + off_desc, c->match_dev + off_valid);
+    FT_HIP(c, hipGetLastError());
+    FT_HIP(c, hipMemcpyAsync(c->match_host + off_desc, c->match_dev + off_desc, 33 * (size_t)n, hipMemcpyDeviceToHost, c->q));
+    FT_HIP(c, hipStreamSynchronize(c->q));
+    memcpy(desc, c->match_host + off_desc, 32 * (size_t)n);
+    memcpy(valid, c->match_host + off_valid, (size_t)n);
+    return FT_OK;
+}
+
 int ft_match_descriptors(ft_ctx* c, const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, ft_match* out, int cap, int* n_out) {
     if (!c || !n_out || n0 < 0 || n1 < 0 || cap < 0 || (cap > 0 && !out) || (n0 > 0 && !desc0) || (n1 > 0 && !desc1)) return FT_E_INVALID;
     if (n0 > 65536 || n1 > 65536) return FT_E_LIMIT;
     *n_out = 0;
     if (n0 == 0 || n1 == 0) return FT_OK;
     FT_HIP(c, hipSetDevice(c->device));
-    const size_t need = (size_t)std::max(n0, n1);
-    if (need > c->match_cap) {
-        FT_HIP(c, hipStreamSynchronize(c->q));
-        if (c->match_dev) (void)hipFree(c->match_dev);
-        if (c->match_host) (void)hipHostFree(c->match_host);
-        c->match_dev = nullptr; c->match_host = nullptr; c->match_cap = 0;
-        const size_t cap_n = align_up(need, 1024);
-        void* p = nullptr;
-        FT_HIP(c, hipMalloc(&p, cap_n * (32 + 8) * 2));
-        c->match_dev = (uint8_t*)p;
-        FT_HIP(c, hipHostMalloc(&p, cap_n * (32 + 8) * 2, hipHostMallocDefault));
-        c->match_host = (uint8_t*)p;
-        c->match_cap = cap_n;
-    }
+    { const int rc = ensure_match_cap(c, (size_t)std::max(n0, n1)); if (rc) return rc; }
     // layout of both blocks: descriptors of set 0, of set 1, neighbour table of set 0, of set 1
     const size_t M = c->match_cap;
     const size_t off_d1 = 32 * M, off_b0 = 64 * M, off_b1 = 72 * M;

@@ -68,7 +68,7 @@ class ft_kernel_time(C.Structure):
 # every symbol include/ft_device.h declares
 SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device",
            "ft_set_frames_device_pyramid", "ft_build_pyramid",
-           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_match_descriptors", "ft_stage_frame", "ft_set_frames_staged_pyramid", "ft_fast_grid", "ft_fast_grid_async",
+           "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_match_descriptors", "ft_compute_descriptors", "ft_stage_frame", "ft_set_frames_staged_pyramid", "ft_fast_grid", "ft_fast_grid_async",
            "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
            "ft_last_hip_error", "ft_device_count"]
@@ -117,6 +117,7 @@ def load_library():
     lib.ft_stage_frame.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t]
     lib.ft_set_frames_staged_pyramid.argtypes = [vp, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip]
     lib.ft_match_descriptors.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.POINTER(ft_match), C.c_int, ip]
+    lib.ft_compute_descriptors.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
     lib.ft_reject_outliers.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
     lib.ft_reject_outliers_async.argtypes = [vp, C.c_int, C.POINTER(ft_match_set), C.c_int, C.c_uint]
     fg = [vp, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ft_keypoint), C.c_int, ip, ip]
@@ -345,6 +346,14 @@ class DeviceContext:
         self._check(self.lib.ft_match_descriptors(self._ctx, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], knn_ratio, out, cap,
                                                   C.byref(n)), "ft_match_descriptors")
         return np.array([(out[i].query, out[i].train, int(out[i].distance)) for i in range(n.value)], dtype=np.int32).reshape(-1, 3)
+
+    def compute_descriptors(self, stream, slot, xy):
+        """xy (n, 2) keypoint positions on level 0.  Returns (desc (n, 32) uint8, valid (n,) uint8)."""
+        p = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        n = p.shape[0]
+        desc, valid = np.zeros((n, 32), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.ft_compute_descriptors(self._ctx, stream, slot, p.ctypes.data, n, desc.ctypes.data, valid.ctypes.data), "ft_compute_descriptors")
+        return desc, valid
 
     # -- FAST --
     def fast_grid(self, streams, slots, threshold=20, grid_x=5, grid_y=5, per_cell=7, cap=None, sync=True):

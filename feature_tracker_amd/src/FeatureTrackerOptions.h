@@ -14,7 +14,7 @@ struct FeatureTrackerOptions {
     int num_cameras = 2;
 
     // ---- tracker ----
-    bool use_klt = true;        // KLT tracking (the descriptor matcher is not part of this build)
+    bool use_klt = true;        // KLT tracking; false: the descriptor tracker (TrackDescriptor)
     int num_pts = 150;          // points extracted and tracked in each image
     int fast_threshold = 20;    // FAST extraction threshold
     int grid_x = 5;             // detection grid columns

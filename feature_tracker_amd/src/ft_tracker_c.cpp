@@ -6,6 +6,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -14,6 +16,7 @@
 #include <new>
 
 #include "FeatureTrackerOptions.h"
+#include "track/TrackDescriptor.h"
 #include "track/TrackKLT.h"
 #include "track/TrackKLTBatch.h"
 
@@ -34,6 +37,7 @@ FeatureTrackerOptions to_options(const ftk_options& o) {
     r.reject_outliers = o.reject_outliers != 0; if (o.ransac_hypotheses > 0) r.ransac_hypotheses = o.ransac_hypotheses;
     r.stereo_extrinsic_seed = o.stereo_extrinsic_seed != 0; r.stereo_threshold = o.stereo_threshold;
     r.drop_fraction = o.drop_fraction;
+    r.use_klt = o.use_klt != 0; if (o.knn_ratio > 0) r.knn_ratio = o.knn_ratio;
     return r;
 }
 
@@ -55,7 +59,7 @@ bool valid_options(const ftk_options* o) {
            o->pyr_levels < FT_MAX_LEVELS && o->win_size >= 3 && o->win_size <= FT_MAX_WIN;
 }
 
-int get_points(TrackKLT& t, int cam, float* xy, uint64_t* ids, int cap) {
+int get_points(TrackBase& t, int cam, float* xy, uint64_t* ids, int cap) {
     const std::vector<KeyPoint> p = t.get_last_points((size_t)cam);
     const std::vector<size_t> id = t.get_last_ids((size_t)cam);
     for (size_t i = 0; i < p.size() && (int)i < cap; i++) {
@@ -79,7 +83,8 @@ void calib_maps(int n_cams, const double* calib8, const double* T, std::map<size
 
 struct ftk_tracker {
     std::unique_ptr<FrontendBackend> be;
-    std::unique_ptr<TrackKLT> trk;
+    std::unique_ptr<TrackBase> trk;   // TrackKLT, or TrackDescriptor when the options say use_klt = 0 (src/test_tracking.cpp:229-230)
+    TrackKLT* klt = nullptr;          // == trk.get() for a KLT tracker
 };
 
 // One stream group = one device context + one TrackKLTBatch + one host driver thread.  Groups share nothing, so
@@ -143,7 +148,12 @@ struct ftk_group {
             }
         }
     }
-    void post_db() {
+    // Handing a set's observations to the writers has a cheap half (take_db: the payload vectors change hands) and a
+    // dear one (queue locks, waking the writer threads).  The driver does the cheap half right after complete() and the
+    // dear one after it has launched the next set's tracking, so that the wake-ups are not on the path from one
+    // tracking result to the next tracking launch.
+    std::unique_ptr<DbJob> taken;   // payload taken, not yet queued
+    void take_db_job() {
         std::unique_ptr<DbJob> job;
         {
             std::lock_guard<std::mutex> lk(wm);
@@ -155,15 +165,23 @@ struct ftk_group {
             wfree.push_back(std::move(job));
             return;
         }
-        job->remaining.store(N_WRITERS, std::memory_order_release);
         {
             std::lock_guard<std::mutex> lk(wm);
-            for (int w = 0; w < N_WRITERS; w++) wq[w].push_back(job.get());
-            wbusy.push_back(std::move(job));
-            w_posted++;
+            w_posted++;   // wait_db() counts a taken set as posted: it must not return before that set is written
+        }
+        taken = std::move(job);
+    }
+    void queue_db_job() {
+        if (!taken) return;
+        taken->remaining.store(N_WRITERS, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(wm);
+            for (int w = 0; w < N_WRITERS; w++) wq[w].push_back(taken.get());
+            wbusy.push_back(std::move(taken));
         }
         wcv.notify_all();
     }
+    void post_db() { take_db_job(); queue_db_job(); }
     void wait_db() {
         long target;
         {
@@ -185,6 +203,9 @@ struct ftk_group {
         driver = std::thread([this] { run(); });
     }
     void shutdown() {
+        if (tm_n && getenv("FT_GROUP_TIMING"))
+            fprintf(stderr, "[group %d+%d] %ld sets: mail %.1f begin %.1f stage %.1f complete %.1f after %.1f us\n", first, n, tm_n, tm[0] / tm_n,
+                    tm[1] / tm_n, tm[2] / tm_n, tm[3] / tm_n, tm[4] / tm_n);
         if (driver.joinable()) {
             {
                 std::lock_guard<std::mutex> lk(m);
@@ -201,9 +222,27 @@ struct ftk_group {
         for (auto& t : writers)
             if (t.joinable()) t.join();
     }
+    // publish frame set `seq` as complete and wake a caller that sleeps on it
+    void publish(long seq) {
+        // sequentially consistent store/load pair: either the waiter sees `done` or this thread sees the waiter
+        done.store(seq);
+        if (waiters.load()) {
+            std::lock_guard<std::mutex> lk(dm);
+            dcv.notify_all();
+        }
+    }
+    // FT_GROUP_TIMING=1: mean microseconds per frame set the driver spends waiting for mail / in begin / stage / complete /
+    // after complete, printed when the group shuts down (a diagnostic for the pipelined feed)
+    double tm[5] = {0, 0, 0, 0, 0};
+    long tm_n = 0;
     void run() {
+        const bool timing = getenv("FT_GROUP_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        long unpublished = 0;   // a completed set whose publication was deferred behind the next set's tracking launch
         for (;;) {
-            const long next = done.load(std::memory_order_relaxed) + 1;
+            const long next = (unpublished ? unpublished : done.load(std::memory_order_relaxed)) + 1;
+            const auto t0 = now();
             // a short spin bridges back-to-back frames; after that sleep: a thread that spins for long steals issue
             // slots from whatever shares its core (the other group's driver, the HIP runtime's own threads)
             // (a caller that feeds one set at a time and waits for it asks for a long spin: wake-ups would dominate its latency)
@@ -214,34 +253,45 @@ struct ftk_group {
                 sleeping.store(1, std::memory_order_release);
                 cv.wait(lk, [&] { return stop || posted.load(std::memory_order_acquire) >= next; });
                 sleeping.store(0, std::memory_order_release);
-                if (stop) return;
+                if (stop) return;   // (nothing is ever left unpublished here: deferral needs the next set in the mailbox)
             }
             Mail& M = mail[next & (MAIL_RING - 1)];
             // nothing else waiting: the caller feeds one set at a time, so keep the detector out of this set's latency
             const bool late_detect = posted.load(std::memory_order_acquire) == next;
+            const auto t1 = now();
             M.rc = batch->begin(M.ts.data(), M.frames.data(), late_detect);
+            const auto t2 = now();
+            // the previous set's deferred chores, now that this set's tracking is queued on the device
+            queue_db_job();
+            if (unpublished) { publish(unpublished); unpublished = 0; }
             // lookahead: if the following set is already in the mailbox, queue its ingest, pyramids and detector now so
             // that the device stays busy while this set's results are processed
             if (M.rc == FT_OK && posted.load(std::memory_order_acquire) > next) {
                 Mail& N = mail[(next + 1) & (MAIL_RING - 1)];
                 M.rc = batch->stage(N.ts.data(), N.frames.data());
             }
+            const auto t3 = now();
             if (M.rc == FT_OK) M.rc = batch->complete();
-            if (late_detect && posted.load(std::memory_order_acquire) == next) {
+            const auto t4 = now();
+            M.tracked = (long long)batch->tracked_features();
+            M.attempted = (long long)batch->attempted_features();
+            const bool more = posted.load(std::memory_order_acquire) > next;
+            if (late_detect && !more) {
                 // one set at a time: a hundred or so observations are written faster here than a writer thread wakes up
                 wait_db();            // (sets handed to the writers earlier come first)
                 batch->flush_db();
+                publish(next);
+            } else if (more && M.rc == FT_OK) {
+                // The next set is waiting: its tracking launch comes first.  This set's observations change hands now
+                // (begin() would otherwise write them itself), the writers are woken and the set is published after
+                // that launch.  The caller cannot be waiting for this set to post the next one: it already has.
+                take_db_job();
+                unpublished = next;
             } else {
                 post_db();   // this set's observations go to the database on the writer threads
+                publish(next);
             }
-            M.tracked = (long long)batch->tracked_features();
-            M.attempted = (long long)batch->attempted_features();
-            // sequentially consistent store/load pair: either the waiter sees `done` or this thread sees the waiter
-            done.store(next);
-            if (waiters.load()) {
-                std::lock_guard<std::mutex> lk(dm);
-                dcv.notify_all();
-            }
+            if (timing) { tm[0] += us(t0, t1); tm[1] += us(t1, t2); tm[2] += us(t2, t3); tm[3] += us(t3, t4); tm[4] += us(t4, now()); tm_n++; }
         }
     }
     // hand frame set `seq` (= posted + 1) to the driver; set seq - MAIL_RING + 1 and older must have been collected
@@ -335,6 +385,7 @@ void ftk_default_options(ftk_options* o) {
     o->reject_outliers = d.reject_outliers; o->ransac_hypotheses = d.ransac_hypotheses;
     o->stereo_extrinsic_seed = d.stereo_extrinsic_seed; o->stereo_threshold = d.stereo_threshold;
     o->drop_fraction = d.drop_fraction;
+    o->use_klt = d.use_klt; o->knn_ratio = d.knn_ratio; o->descriptor_ransac_on_pairs = 0;
 }
 
 const char* ftk_backend_name(void) { return ftk_backend_label(); }
@@ -347,7 +398,15 @@ int ftk_tracker_create(ftk_tracker** out, int device, const ftk_options* o, int 
         void* dctx = nullptr;
         t->be.reset(ftk_make_backend(device, limits_for(*o, 2, max_width, max_height), &dctx));
         if (!t->be) return FT_E_NODEVICE;
-        t->trk.reset(new TrackKLT(t->be.get(), to_options(*o), 0, 0));
+        const FeatureTrackerOptions fo = to_options(*o);
+        if (fo.use_klt) {
+            t->klt = new TrackKLT(t->be.get(), fo, 0, 0);
+            t->trk.reset(t->klt);
+        } else {
+            TrackDescriptor* d = new TrackDescriptor(t->be.get(), fo.num_pts, 0, fo.fast_threshold, fo.grid_x, fo.grid_y, fo.knn_ratio, 0);
+            d->set_ransac_on_matched_pairs(o->descriptor_ransac_on_pairs != 0);
+            t->trk.reset(d);
+        }
         *out = t.release();
         return FT_OK;
     } catch (const std::bad_alloc&) {
@@ -381,8 +440,8 @@ int ftk_tracker_feed_stereo(ftk_tracker* t, double timestamp, const uint8_t* lef
 }
 
 int ftk_tracker_feed_monocular(ftk_tracker* t, double timestamp, const uint8_t* img, int w, int h, size_t stride, int cam) {
-    if (!t || !img || w < 1 || h < 1 || cam < 0 || cam > 1) return FT_E_INVALID;
-    return t->trk->feed_monocular(timestamp, Image8(img, w, h, stride), (size_t)cam);
+    if (!t || !t->klt || !img || w < 1 || h < 1 || cam < 0 || cam > 1) return FT_E_INVALID;   // the descriptor tracker is stereo only
+    return t->klt->feed_monocular(timestamp, Image8(img, w, h, stride), (size_t)cam);
 }
 
 int ftk_tracker_get_points(ftk_tracker* t, int cam, float* xy, uint64_t* ids, int cap) {
@@ -392,14 +451,14 @@ int ftk_tracker_get_points(ftk_tracker* t, int cam, float* xy, uint64_t* ids, in
 
 int ftk_tracker_database_size(ftk_tracker* t) { return t ? (int)t->trk->get_feature_database()->size() : FT_E_INVALID; }
 
-static int get_track(TrackKLT& trk, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
+static int get_track(TrackBase& trk, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
 
 int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap) {
     if (!t) return FT_E_INVALID;
     return get_track(*t->trk, id, cam, uvn4, timestamps, cap);
 }
 
-static int get_track(TrackKLT& trk, uint64_t id, int cam, float* uvn4, double* timestamps, int cap) {
+static int get_track(TrackBase& trk, uint64_t id, int cam, float* uvn4, double* timestamps, int cap) {
     Feature* f = trk.get_feature_database()->get_feature((size_t)id);
     if (!f || !f->timestamps.count((size_t)cam)) return 0;
     const auto& ts = f->timestamps.at((size_t)cam);

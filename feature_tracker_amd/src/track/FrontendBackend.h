@@ -27,6 +27,11 @@ public:
     virtual int lk_track_async(int n_jobs, const ft_lk_job* jobs, const ft_lk_params* prm) = 0;
     virtual int fast_grid_async(int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
                                 int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts) = 0;
+    // descriptor tracker: descriptors at keypoints of level 0, 2-NN Hamming matching with ratio and symmetry tests,
+    // outlier rejection on point pairs the caller holds (all three complete before they return)
+    virtual int compute_descriptors(int stream, int slot, const float* xy, int n, uint8_t* desc, uint8_t* valid) = 0;
+    virtual int match_descriptors(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, ft_match* out, int cap, int* n_out) = 0;
+    virtual int reject_outliers(int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed) = 0;
     virtual void homography(const float* K4, const float* R_p_c, float* H) = 0;
     virtual int sync() = 0;
     // partial wait: fence() marks the end of the queue, wait(token) returns once the queue has passed the mark and the

@@ -45,6 +45,15 @@ public:
                         ft_keypoint* out, int cap, int* n_out, int* cell_counts) override {
         return ft_fast_grid_async(ctx_, n, streams, slots, threshold, grid_x, grid_y, per_cell, out, cap, n_out, cell_counts);
     }
+    int compute_descriptors(int stream, int slot, const float* xy, int n, uint8_t* desc, uint8_t* valid) override {
+        return ft_compute_descriptors(ctx_, stream, slot, xy, n, desc, valid);
+    }
+    int match_descriptors(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, ft_match* out, int cap, int* n_out) override {
+        return ft_match_descriptors(ctx_, desc0, n0, desc1, n1, knn_ratio, out, cap, n_out);
+    }
+    int reject_outliers(int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed) override {
+        return ft_reject_outliers(ctx_, n_sets, sets, hypotheses, seed);
+    }
     void homography(const float* K4, const float* R_p_c, float* H) override { ft_homography(K4, R_p_c, H); }
     int sync() override { return ft_sync(ctx_); }
     int fence(uint64_t* token) override { return ft_fence(ctx_, token); }

@@ -17,7 +17,8 @@ class ftk_options(C.Structure):
                 ("lk_eps", C.c_double), ("lk_min_eig", C.c_double), ("use_gyro_seed", C.c_int), ("forward_backward", C.c_int),
                 ("fb_thresh", C.c_float), ("speculative_detect", C.c_int),
                 ("reject_outliers", C.c_int), ("ransac_hypotheses", C.c_int),
-                ("stereo_extrinsic_seed", C.c_int), ("stereo_threshold", C.c_double), ("drop_fraction", C.c_double)]
+                ("stereo_extrinsic_seed", C.c_int), ("stereo_threshold", C.c_double), ("drop_fraction", C.c_double),
+                ("use_klt", C.c_int), ("knn_ratio", C.c_double), ("descriptor_ransac_on_pairs", C.c_int)]
 
 
 SYMBOLS = ["ftk_default_options", "ftk_tracker_create", "ftk_tracker_destroy", "ftk_tracker_set_calibration",

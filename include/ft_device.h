@@ -198,14 +198,25 @@ int ft_fast_grid(ft_ctx* ctx, int n, const int* streams, const int* slots, int t
 int ft_fast_grid_async(ft_ctx* ctx, int n, const int* streams, const int* slots, int threshold, int grid_x, int grid_y,
                        int per_cell, ft_keypoint* out, int cap, int* n_out, int* cell_counts);
 
+/* 256-bit binary descriptors at n keypoints of level 0 of (stream, slot): the step orb->compute(img, pts, desc) of
+ * TrackDescriptor::perform_detection_stereo (src/track/TrackDescriptor.cpp:218-219).  ORB's sampling table lives inside
+ * OpenCV and is not available to this build, so the descriptor is the library's own BRIEF-style one with ORB's geometry
+ * (parity unpinned): 5x5 binomial smoothing, 256 comparisons of smoothed intensities at pseudo-random offset pairs inside
+ * the 31x31 patch (offset coordinate k of test i = mix32(0xB5297A4D + 4 i + k) mod 31 - 15 with the 32-bit mixer
+ * x ^= x >> 16, x *= 0x7feb352d, x ^= x >> 15, x *= 0x846ca68b, x ^= x >> 16), bit i = S(p1) < S(p2) in byte i / 8 at
+ * bit i % 8, no rotation.  xy: n*2 pixel positions (their integer parts are used); desc: n*32 bytes; valid[i] = 0 and a
+ * zero descriptor for a keypoint closer than 17 pixels to the border (ORB drops those keypoints).  Synchronous;
+ * n <= 65536. */
+int ft_compute_descriptors(ft_ctx* ctx, int stream, int slot, const float* xy, int n, uint8_t* desc, uint8_t* valid);
+
 /* Matching of two sets of 256-bit binary descriptors (ORB rows, 32 bytes each) as TrackDescriptor::robust_match does
  * it before its RANSAC (src/track/TrackDescriptor.cpp:249-265, :309-354): the two nearest neighbours of every
  * descriptor in the other set, both ways (cv::BFMatcher(NORM_HAMMING).knnMatch(…, 2); equal distances: the lower
  * index first), the ratio test distance[0] / distance[1] > knn_ratio -> dropped (also dropped: fewer than two
  * neighbours), and the symmetry test (query -> train kept only if train's own surviving match is query).  Accepted
  * matches are written in query order; *n_out is their number (at most cap are written).  The reference's RANSAC tail
- * (:267-304) is ft_reject_outliers on the matched points.  Descriptor extraction (cv::ORB::compute, :218-219) is not
- * part of this library.  Synchronous; n0, n1 <= 65536. */
+ * (:267-304) is ft_reject_outliers on the matched points; descriptor extraction (:218-219) is ft_compute_descriptors.
+ * Synchronous; n0, n1 <= 65536. */
 int ft_match_descriptors(ft_ctx* ctx, const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio,
                          ft_match* out, int cap, int* n_out);
 

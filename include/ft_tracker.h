@@ -38,6 +38,12 @@ typedef struct ftk_options {
     double stereo_threshold;    /* px, src/track/TrackMsckfVio.h:217 -> 3 */
     double drop_fraction;       /* load generator, no reference counterpart: forget this fraction of the active tracks at the
                                    start of every feed so that the detector must replenish on every frame -> 0 */
+    int use_klt;                /* src/FeatureTrackerOptions.h:33 -> 1; 0 selects the descriptor tracker (TrackDescriptor, stereo only),
+                                   src/test_tracking.cpp:229-230 */
+    double knn_ratio;           /* descriptor tracker: ratio test of the two nearest neighbours, src/FeatureTrackerOptions.h:51 -> 0.85 */
+    int descriptor_ransac_on_pairs;   /* descriptor tracker: 0 = the RANSAC step as the reference is written (it compares a point
+                                   set with itself, src/track/TrackDescriptor.cpp:284-285, and rejects nothing); 1 = outlier
+                                   rejection on the matched pairs -> 0 */
 } ftk_options;
 
 typedef struct ftk_tracker ftk_tracker;

@@ -891,6 +891,32 @@ void fto_stereo_check(const float* cam0_xy, const float* cam1_xy, uint8_t* statu
     }
 }
 
+int fto_compute_descriptors(const uint8_t* img, int w, int h, size_t stride, const float* xy, int n, uint8_t* desc, uint8_t* valid) {
+    if (!img || n < 0 || (n > 0 && (!xy || !desc || !valid))) return -1;
+    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+    auto off = [&](int i, int k) { return (int)(mix(0xB5297A4Du + 4u * (uint32_t)i + (uint32_t)k) % 31u) - 15; };
+    // 5x5 binomial smoothing at one pixel (the whole window lies inside the image for every sample of a valid keypoint)
+    auto smooth = [&](int x, int y) {
+        static const int k5[5] = {1, 4, 6, 4, 1};
+        int s = 0;
+        for (int j = -2; j <= 2; j++)
+            for (int i = -2; i <= 2; i++) s += k5[j + 2] * k5[i + 2] * img[(size_t)(y + j) * stride + (size_t)(x + i)];
+        return (s + 128) >> 8;
+    };
+    for (int p = 0; p < n; p++) {
+        const int cx = (int)xy[2 * p], cy = (int)xy[2 * p + 1];
+        uint8_t* d = desc + (size_t)p * 32;
+        for (int b = 0; b < 32; b++) d[b] = 0;
+        if (cx < 17 || cy < 17 || cx >= w - 17 || cy >= h - 17) { valid[p] = 0; continue; }
+        valid[p] = 1;
+        for (int i = 0; i < 256; i++) {
+            const int a = smooth(cx + off(i, 0), cy + off(i, 1)), b = smooth(cx + off(i, 2), cy + off(i, 3));
+            if (a < b) d[i >> 3] |= (uint8_t)(1u << (i & 7));
+        }
+    }
+    return 0;
+}
+
 int fto_match_descriptors(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, int* out_qtd, int cap) {
     struct Two { int i1 = -1, d1 = 0, i2 = -1, d2 = 0; };
     auto knn2 = [](const uint8_t* q, int nq, const uint8_t* t, int nt) {

@@ -134,6 +134,14 @@ void fto_stereo_seed(const float* cam0_xy, int n, const double* calib8_cam0, con
 void fto_stereo_check(const float* cam0_xy, const float* cam1_xy, uint8_t* status, int n, const double* calib8_cam0,
                       const double* calib8_cam1, const double* Rt12, int w, int h, double threshold);
 
+/* 256-bit binary descriptors at keypoints, the step orb->compute() of TrackDescriptor::perform_detection_stereo
+ * (src/track/TrackDescriptor.cpp:218-219).  ORB's sampling table is inside OpenCV and not available, so this is the
+ * build's own BRIEF-style descriptor with ORB's geometry (parity unpinned): 5x5 binomial smoothing ((sum + 128) >> 8), test i
+ * compares the smoothed values at two offsets in [-15, 15]^2, coordinate k of test i = mix32(0xB5297A4D + 4 i + k) mod 31
+ * - 15 (mix32 as in fto_reject_outliers), bit i = S(p1) < S(p2) in byte i / 8 at bit i % 8, no rotation; a keypoint
+ * closer than 17 px to the border gets valid = 0 and a zero descriptor.  Positions are truncated to whole pixels. */
+int fto_compute_descriptors(const uint8_t* img, int w, int h, size_t stride, const float* xy, int n, uint8_t* desc, uint8_t* valid);
+
 /* Descriptor matching of TrackDescriptor::robust_match before its RANSAC (src/track/TrackDescriptor.cpp:249-265,
  * :309-354) on 32-byte binary descriptors: 2 nearest neighbours by Hamming distance both ways (equal distances: the
  * lower index first), ratio test first / second > knn_ratio -> dropped, symmetry test.  out_qtd receives

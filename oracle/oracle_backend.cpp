@@ -136,6 +136,25 @@ public:
         for (int r : rcs) if (r < 0) return FT_E_INVALID;
         return FT_OK;
     }
+    int compute_descriptors(int stream, int slot, const float* xy, int n, uint8_t* desc, uint8_t* valid) override {
+        Slot* S = at(stream, slot);
+        if (!S || n < 0) return FT_E_INVALID;
+        if (S->img.empty()) return FT_E_STATE;
+        return fto_compute_descriptors(S->img.data(), S->w, S->h, (size_t)S->w, xy, n, desc, valid) == 0 ? FT_OK : FT_E_INVALID;
+    }
+    int match_descriptors(const uint8_t* desc0, int n0, const uint8_t* desc1, int n1, float knn_ratio, ft_match* out, int cap, int* n_out) override {
+        std::vector<int> qtd(3 * (size_t)std::max(cap, 1));
+        const int n = fto_match_descriptors(desc0, n0, desc1, n1, knn_ratio, qtd.data(), cap);
+        for (int i = 0; i < n && i < cap; i++) { out[i].query = qtd[3 * i]; out[i].train = qtd[3 * i + 1]; out[i].distance = (float)qtd[3 * i + 2]; }
+        *n_out = n;
+        return FT_OK;
+    }
+    int reject_outliers(int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed) override {
+        for (int j = 0; j < n_sets; j++)
+            if (sets[j].n > 0)
+                fto_reject_outliers(sets[j].prev_xy, sets[j].next_xy, sets[j].status, sets[j].n, sets[j].calib_prev, sets[j].calib_next, hypotheses, seed, nullptr);
+        return FT_OK;
+    }
     void homography(const float* K4, const float* R, float* H) override { fto_homography(K4, R, H); }
     int sync() override { return FT_OK; }
     // every call of this backend completes before it returns

@@ -59,6 +59,11 @@ public:
         int r = trip(FAST);
         return r ? r : in->fast_grid_async(n, s, l, t, gx, gy, pc, o, cap, no, cc);
     }
+    int compute_descriptors(int s, int l, const float* xy, int n, uint8_t* d, uint8_t* v) override { return in->compute_descriptors(s, l, xy, n, d, v); }
+    int match_descriptors(const uint8_t* d0, int n0, const uint8_t* d1, int n1, float r, ft_match* o, int cap, int* no) override {
+        return in->match_descriptors(d0, n0, d1, n1, r, o, cap, no);
+    }
+    int reject_outliers(int n, const ft_match_set* s, int h, unsigned seed) override { return in->reject_outliers(n, s, h, seed); }
     void homography(const float* K4, const float* R, float* H) override { in->homography(K4, R, H); }
     int sync() override { int r = trip(SYNC); return r ? r : in->sync(); }
     int fence(uint64_t* t) override { return in->fence(t); }

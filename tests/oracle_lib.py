@@ -234,6 +234,18 @@ def stereo_check(cam0_xy, cam1_xy, status, calib8_cam0, calib8_cam1, Rt12, w, h,
     return st
 
 
+def compute_descriptors(img, xy):
+    """(desc (n, 32) uint8, valid (n,) uint8) of the build's BRIEF-style descriptor at the keypoints xy (n, 2)."""
+    img = _u8(img)
+    h, w = img.shape
+    p = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    desc, valid = np.zeros((p.shape[0], 32), dtype=np.uint8), np.zeros(p.shape[0], dtype=np.uint8)
+    L = lib()
+    L.fto_compute_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.fto_compute_descriptors(img.ctypes.data, w, h, img.strides[0], p.ctypes.data, p.shape[0], desc.ctypes.data, valid.ctypes.data)
+    return desc, valid
+
+
 def match_descriptors(desc0, desc1, knn_ratio=0.7):
     """(m, 3) int32 rows (query, train, distance): 2-NN Hamming both ways + ratio test + symmetry test."""
     a = np.ascontiguousarray(desc0, dtype=np.uint8).reshape(-1, 32)

@@ -272,7 +272,8 @@ def test_batch_threads_cpp_under_thread_sanitizer(tmp_path):
     exe = str(tmp_path / "test_batch_threads")
     src = [os.path.join(ROOT, "tests", "cpp", "test_batch_threads.cpp"), os.path.join(ROOT, "oracle", "oracle_backend.cpp"),
            os.path.join(ROOT, "oracle", "ft_oracle.cpp"), os.path.join(ROOT, "feature_tracker_amd", "src", "ft_tracker_c.cpp"),
-           os.path.join(ROOT, "feature_tracker_amd", "src", "track", "TrackKLT.cpp"), os.path.join(ROOT, "feature_tracker_amd", "csrc", "ft_synth.cpp")]
+           os.path.join(ROOT, "feature_tracker_amd", "src", "track", "TrackKLT.cpp"),
+           os.path.join(ROOT, "feature_tracker_amd", "src", "track", "TrackDescriptor.cpp"), os.path.join(ROOT, "feature_tracker_amd", "csrc", "ft_synth.cpp")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "feature_tracker_amd", "src"), "-I" + os.path.join(ROOT, "oracle"), "-o", exe] + src + ["-pthread"])
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"))
