@@ -99,7 +99,7 @@ struct ft_ctx {
 
     // FAST scratch
     uint32_t* cand = nullptr; size_t cand_entries_per_img = 0;
-    int* cand_count = nullptr;          // [n_streams][max_grid_cells]
+    int* cand_count = nullptr;          // [n_streams][max_grid_cells], FAST_COUNT_STRIDE ints apart
     uint8_t* fast_out_host_dev[2] = {nullptr, nullptr};   // device-side addresses of the pinned result buffers
     // detector outputs are double-buffered on the host side so that the detector of the next frame set can be
     // enqueued before the previous set's outputs have been delivered
@@ -427,10 +427,10 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     if (hipMalloc(&p, sizeof(uint32_t) * c->cand_entries_per_img * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
     c->cand = (uint32_t*)p;
     const size_t cells_total = (size_t)lim->n_streams * lim->max_grid_cells;
-    if (hipMalloc(&p, sizeof(int) * cells_total) != hipSuccess) return fail(FT_E_NOMEM);
+    if (hipMalloc(&p, sizeof(int) * cells_total * FAST_COUNT_STRIDE) != hipSuccess) return fail(FT_E_NOMEM);
     c->cand_count = (int*)p;
     // the per-cell candidate counters start at zero and every top-k pass leaves them at zero again
-    if (hipMemset(c->cand_count, 0, sizeof(int) * cells_total) != hipSuccess) return fail(FT_E_HIP);
+    if (hipMemset(c->cand_count, 0, sizeof(int) * cells_total * FAST_COUNT_STRIDE) != hipSuccess) return fail(FT_E_HIP);
     c->fast_out_bytes = align_up(sizeof(ft_keypoint) * cells_total * lim->max_per_cell, 16) + sizeof(int) * cells_total * 2 + 256;
     for (int i = 0; i < ft_ctx::FAST_RING; i++) {
         if (hipHostMalloc(&p, c->fast_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
@@ -925,7 +925,7 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     EventPair ep;
     prof_begin(c, 2, ep);
     const int tiles = fast_tiles_x(w) * fast_tiles_y(h);
-    hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(256), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
+    hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(64), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
     hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, c->q, G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());

@@ -5,8 +5,8 @@
 // in the 3-pixel band inside each cell border and NMS never sees a neighbouring cell's score: the score map is
 // therefore zero outside the cell insets, and a single image-wide 3x3 strict-maximum test equals per-cell NMS.
 //
-//   fast_detect_kernel : u8 image -> per-cell candidate lists (score + position keys, unordered); reads level 0
-//                        once, keeps pixels and scores in LDS, one global atomic per NMS survivor.  The kernel is
+//   fast_detect_kernel : u8 image -> per-cell candidate lists (score + position keys, unordered); one wavefront per
+//                        tile, pixels and scores in LDS, one global atomic per NMS survivor.  The kernel is
 //                        bound by vector-instruction issue, so the pre-test handles four pixels per lane from
 //                        dword LDS reads and the exact strength runs only on compacted candidates.
 //   fast_topk_kernel   : one wavefront per cell extracts the first `per_cell` candidates in the total order
@@ -15,6 +15,10 @@
 #include "ft_common.hpp"
 
 namespace ftd {
+
+// Every per-cell candidate counter has a 128-byte line of its own: read-modify-write operations on one line are
+// serialised by the memory system, and with packed counters a few dozen lines took every atomic of a launch.
+constexpr int FAST_COUNT_STRIDE = 32;   // ints
 
 struct FastGrid {
     int w, h;
@@ -37,13 +41,11 @@ __device__ __forceinline__ uint32_t fast_compass2(uint32_t c, uint32_t n, uint32
     const fd_v2u C = __builtin_bit_cast(fd_v2u, c), N = __builtin_bit_cast(fd_v2u, n), S = __builtin_bit_cast(fd_v2u, s);
     const fd_v2u W = __builtin_bit_cast(fd_v2u, w), E = __builtin_bit_cast(fd_v2u, e), T = __builtin_bit_cast(fd_v2u, thr2);
     const fd_v2u lo = __builtin_elementwise_sub_sat(C, T), hi = C + T;
-    const fd_v2u dark = __builtin_elementwise_min(
-        __builtin_elementwise_max(__builtin_elementwise_sub_sat(lo, N), __builtin_elementwise_sub_sat(lo, S)),
-        __builtin_elementwise_max(__builtin_elementwise_sub_sat(lo, E), __builtin_elementwise_sub_sat(lo, W)));
-    const fd_v2u bright = __builtin_elementwise_min(
-        __builtin_elementwise_max(__builtin_elementwise_sub_sat(N, hi), __builtin_elementwise_sub_sat(S, hi)),
-        __builtin_elementwise_max(__builtin_elementwise_sub_sat(E, hi), __builtin_elementwise_sub_sat(W, hi)));
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright));
+    // darker:   (lo > N or lo > S) and (lo > E or lo > W)  <=>  lo > max(min(N, S), min(E, W))
+    // brighter: (N > hi or S > hi) and (E > hi or W > hi)  <=>  min(max(N, S), max(E, W)) > hi
+    const fd_v2u dark = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_max(__builtin_elementwise_min(N, S), __builtin_elementwise_min(E, W)));
+    const fd_v2u bright = __builtin_elementwise_sub_sat(__builtin_elementwise_min(__builtin_elementwise_max(N, S), __builtin_elementwise_max(E, W)), hi);
+    return __builtin_bit_cast(uint32_t, dark) | __builtin_bit_cast(uint32_t, bright);
 }
 
 // strength = max over the 16 arcs of 9 contiguous circle pixels of min(d) (darker arc) or min(-d) (brighter arc),
@@ -72,14 +74,17 @@ __device__ inline uint32_t fast_key(int score, int ly, int lx) {
     return ((uint32_t)score << 24) | ((uint32_t)(4095 - ly) << 12) | (uint32_t)(4095 - lx);
 }
 
-// Detector tile geometry.  A workgroup reports the corners of a 60x62 output region whose first column is 2 mod 4
-// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x64
-// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 62: exactly 16 dwords x 64
-// rows = four 4-pixel tasks per thread, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the
-// radius of the circle and is staged from column CX0 - 8 in 8-byte groups.
-constexpr int FD_ROUNDS = 4;                     // 16 container rows per round of the 256 threads
-constexpr int FD_OW = 60, FD_OH = 16 * FD_ROUNDS - 2;   // output region
-constexpr int FD_CW = 64, FD_CH = 16 * FD_ROUNDS;       // score container
+// Detector tile geometry.  One wavefront owns one tile and shares nothing with other wavefronts (no workgroup barrier:
+// a wavefront that waits for its pixels or for LDS is covered by the seven others of its SIMD, not held up by the
+// slowest wavefront of a workgroup).  A tile reports the corners of a 60x30 output region whose first column is 2 mod 4
+// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x32
+// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 30: exactly 16 dwords x 32 rows
+// = eight 4-pixel tasks per lane, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the radius of
+// the circle and is staged from column CX0 - 8 in 8-byte groups.  (Measured on 64 images of 752x480: tiles of 14 and
+// of 30 rows take the same time within 2 %; the taller tile stages 1.7 instead of 2.1 bytes per output pixel.)
+constexpr int FD_ROUNDS = 8;                     // 4 container rows per round of the 64 lanes
+constexpr int FD_OW = 60, FD_OH = 4 * FD_ROUNDS - 2;    // output region
+constexpr int FD_CW = 64, FD_CH = 4 * FD_ROUNDS;        // score container
 constexpr int FD_PPITCH = 80;                    // pixel tile row: columns CX0-8 .. CX0+71
 constexpr int FD_PROWS = FD_CH + 6;              // rows OY-4 .. OY+33
 constexpr int FD_GROUPS = FD_PPITCH / 8;         // 8-byte groups per pixel row
@@ -90,17 +95,22 @@ struct __attribute__((packed)) FdU2Unaligned { uint32_t a, b; };
 __host__ __device__ inline int fast_tiles_x(int w) { return (max(w - 2, 1) + FD_OW - 1) / FD_OW; }
 __host__ __device__ inline int fast_tiles_y(int h) { return (h + FD_OH - 1) / FD_OH; }
 
+// LDS operations of one wavefront complete in order; this only pins the compiler's ordering between the phases
+__device__ __forceinline__ void fd_phase_fence() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Fused detector: the pixel tile is staged in LDS once; a cheap compass test on four pixels per lane compacts the
 // candidates; the exact corner strength is evaluated only for those (dense lanes); strict 3x3 maxima of the LDS score
 // tile go straight to the per-cell candidate lists.  No score map in HBM.
-__global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L, FastGrid G, uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
+__global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L, FastGrid G, uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
     __shared__ __attribute__((aligned(16))) uint8_t pix[FD_PROWS * FD_PPITCH];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FD_CH * FD_CW];
     __shared__ uint16_t list[FD_LIST];
     __shared__ __attribute__((aligned(4))) uint8_t col_ok[FD_CW];   // column lies in the inset of some cell
     __shared__ uint8_t row_ok[FD_CH];                               // row lies in the inset of some cell
-    __shared__ int list_n;
-    const int t = threadIdx.x;
+    const int lane = threadIdx.x;
     // work list: (image, tile row, tile column), images outermost
     const int tiles_x = fast_tiles_x(G.w), tiles_y = fast_tiles_y(G.h);
     const int item = xcd_item(blockIdx.x, tiles_x * tiles_y * L.n);
@@ -111,24 +121,23 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
     const uint8_t* __restrict__ img = level_img(A, slot, 0);
     const uint32_t pitch = A.lv[0].img_pitch;
 
-    // ---- stage pixels: a wavefront load covers 6 rows x 10 groups of 8 bytes; 3 rounds x 4 waves = 72 rows.
+    // ---- stage pixels: 38 rows x 10 groups of 8 bytes = 380 loads, six per lane, all issued before the first is used.
     //      Rows are clamped into the image and the group left of the image is clamped to column 0: only insets are
     //      ever evaluated, and an inset pixel's circle lies inside the image.  No byte outside [0, w) of a row is
     //      read: a group that straddles the row end is loaded from the last 8 bytes of the row and shifted into
     //      place, a group past the row end is not loaded at all (the image may be a caller's buffer with stride w). ----
     {
-        const int lane = t & 63, wv = t >> 6;
-        const int rg = lane / FD_GROUPS, c8 = lane - rg * FD_GROUPS;
-        const int gx = max(CX0 - 8 + 8 * c8, 0);
-        // 0: whole group inside the row, 1: straddles the row end (w >= 8), 2: nothing to load, 3: row shorter than a group
-        const int mode = gx + 8 <= G.w ? 0 : (gx >= G.w ? 2 : (G.w >= 8 ? 1 : 3));
-        const int ld_x = mode == 1 ? G.w - 8 : gx;
-        const uint32_t sh = mode == 1 ? 8u * (uint32_t)(gx - ld_x) : 0u;
-        constexpr int SR = (FD_PROWS + 23) / 24;   // staging rounds: 4 waves x 6 rows each
+        constexpr int SR = (FD_PROWS * FD_GROUPS + 63) / 64;
         uint2 v[SR];
 #pragma unroll
         for (int k = 0; k < SR; k++) {
-            const int row = min(wv * 6 + rg + 24 * k, FD_PROWS - 1);
+            const int g = min(lane + 64 * k, FD_PROWS * FD_GROUPS - 1);
+            const int row = g / FD_GROUPS, c8 = g - row * FD_GROUPS;
+            const int gx = max(CX0 - 8 + 8 * c8, 0);
+            // 0: whole group inside the row, 1: straddles the row end (w >= 8), 2: nothing to load, 3: row shorter than a group
+            const int mode = gx + 8 <= G.w ? 0 : (gx >= G.w ? 2 : (G.w >= 8 ? 1 : 3));
+            const int ld_x = mode == 1 ? G.w - 8 : gx;
+            const uint32_t sh = mode == 1 ? 8u * (uint32_t)(gx - ld_x) : 0u;
             const int gy = min(max(OY - 4 + row, 0), G.h - 1);
             const uint8_t* src = img + ((uint32_t)gy * pitch + (uint32_t)ld_x);
             if (mode <= 1) {
@@ -145,34 +154,35 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
         }
 #pragma unroll
         for (int k = 0; k < SR; k++) {
-            const int row = wv * 6 + rg + 24 * k;
-            if (lane < 6 * FD_GROUPS && row < FD_PROWS) *reinterpret_cast<uint2*>(&pix[row * FD_PPITCH + 8 * c8]) = v[k];
+            const int g = lane + 64 * k;
+            if (g < FD_PROWS * FD_GROUPS) reinterpret_cast<uint2*>(pix)[g] = v[k];   // FD_PPITCH = 8 * FD_GROUPS: groups are contiguous
         }
     }
 #pragma unroll
-    for (int k = 0; k < FD_CH * FD_CW / 2048; k++) reinterpret_cast<uint2*>(sc)[t + 256 * k] = make_uint2(0u, 0u);   // the whole score tile
-    if (t == 0) list_n = 0;
+    for (int k = 0; k < FD_CH * FD_CW / 512; k++) reinterpret_cast<uint2*>(sc)[lane + 64 * k] = make_uint2(0u, 0u);   // the whole score tile
     // cell membership is separable: one division per column and per row of the container instead of two per pixel
-    if (t < FD_CW) {
-        const int gx = CX0 + t;
+    {
+        const int gx = CX0 + lane;
         const int cxi = fast_cell_of(gx, G.size_x, G.inv_x), lx = gx - cxi * G.size_x;
-        col_ok[t] = (gx < G.w && cxi < G.ct_cols && lx >= 3 && lx < G.size_x - 3) ? 1 : 0;
-    } else if (t >= 128 && t < 128 + FD_CH) {
-        const int gy = OY - 1 + (t - 128);
-        const int cyi = gy >= 0 ? fast_cell_of(gy, G.size_y, G.inv_y) : 0, ly = gy - cyi * G.size_y;
-        row_ok[t - 128] = (gy >= 0 && gy < G.h && cyi < G.ct_rows && ly >= 3 && ly < G.size_y - 3) ? 1 : 0;
+        col_ok[lane] = (gx < G.w && cxi < G.ct_cols && lx >= 3 && lx < G.size_x - 3) ? 1 : 0;
+        if (lane < FD_CH) {
+            const int gy = OY - 1 + lane;
+            const int cyi = gy >= 0 ? fast_cell_of(gy, G.size_y, G.inv_y) : 0, ly = gy - cyi * G.size_y;
+            row_ok[lane] = (gy >= 0 && gy < G.h && cyi < G.ct_rows && ly >= 3 && ly < G.size_y - 3) ? 1 : 0;
+        }
     }
-    __syncthreads();
+    fd_phase_fence();
 
     // ---- compass test, four pixels per task as two packed pairs ----
     const int thr = G.threshold;
     const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
-    const int d = t & 15;                                                    // container dword column of this thread
+    const int d = lane & 15;                                                 // container dword column of this lane
     const uint32_t colbytes = *reinterpret_cast<const uint32_t*>(&col_ok[4 * d]);   // one byte per column
     const uint32_t colbits = (colbytes & 1u) | ((colbytes >> 7) & 2u) | ((colbytes >> 14) & 4u) | ((colbytes >> 21) & 8u);
+    int n_list = 0;                                                          // uniform: entries in the candidate list
 #pragma unroll
     for (int round = 0; round < FD_ROUNDS; round++) {
-        const int r = (t >> 4) + 16 * round;                                 // container row
+        const int r = (lane >> 4) + 4 * round;                               // container row
         uint32_t hits = 0;
         if (colbits != 0 && row_ok[r]) {
             const uint8_t* p = &pix[(r + 3) * FD_PPITCH + 8 + 4 * d];
@@ -189,63 +199,67 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(ArenaDesc A, ImgList L
             hits = ((m01 & 0xffffu) ? 1u : 0u) | ((m01 >> 16) ? 2u : 0u) | ((m23 & 0xffffu) ? 4u : 0u) | ((m23 >> 16) ? 8u : 0u);
             hits &= colbits;
         }
-        // Compaction, one LDS atomic per wavefront: the wave's entries are laid out by pixel position within the task
-        // (all first pixels, then all second pixels, ...), each group ranked with a ballot.  The list is unordered anyway.
-        {
+        // Compaction without atomics (the list belongs to this wavefront): the round's entries are laid out by pixel
+        // position within the task (all first pixels, then all second pixels, ...), each group ranked with a ballot.
+        if (__ballot(hits != 0u) != 0ull) {
             const uint64_t b0 = __ballot(hits & 1u), b1 = __ballot(hits & 2u), b2 = __ballot(hits & 4u), b3 = __ballot(hits & 8u);
             const int n0 = __builtin_popcountll(b0), n1 = __builtin_popcountll(b1), n2 = __builtin_popcountll(b2), n3 = __builtin_popcountll(b3);
-            const int total = n0 + n1 + n2 + n3;
-            if (total) {   // uniform for the wave
-                int base = 0;
-                if ((t & 63) == 0) base = atomicAdd(&list_n, total);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const uint16_t key = (uint16_t)((r << 6) | (4 * d));
-                if (hits & 1u) list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))] = key;
-                if (hits & 2u) list[base + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))] = key | 1;
-                if (hits & 4u) list[base + n0 + n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u))] = key | 2;
-                if (hits & 8u) list[base + n0 + n1 + n2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, 0u))] = key | 3;
-            }
+            const uint16_t key = (uint16_t)((r << 6) | (4 * d));
+            if (hits & 1u) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))] = key;
+            if (hits & 2u) list[n_list + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))] = key | 1;
+            if (hits & 4u) list[n_list + n0 + n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u))] = key | 2;
+            if (hits & 8u) list[n_list + n0 + n1 + n2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, 0u))] = key | 3;
+            n_list += n0 + n1 + n2 + n3;
         }
     }
-    __syncthreads();
+    fd_phase_fence();
 
-    // ---- exact strength for the compacted candidates ----
-    const int n_list = list_n;
-    for (int c = t; c < n_list; c += 256) {
-        const int i = list[c];
-        const int sj = i >> 6, si = i & 63;
-        const uint8_t* p = &pix[(sj + 3) * FD_PPITCH + 8 + si];
-        const int v = p[0];
-        int dd[16];
-        dd[0] = v - p[3 * FD_PPITCH];      dd[1] = v - p[3 * FD_PPITCH + 1];   dd[2] = v - p[2 * FD_PPITCH + 2];   dd[3] = v - p[FD_PPITCH + 3];
-        dd[4] = v - p[3];                  dd[5] = v - p[-FD_PPITCH + 3];      dd[6] = v - p[-2 * FD_PPITCH + 2];  dd[7] = v - p[-3 * FD_PPITCH + 1];
-        dd[8] = v - p[-3 * FD_PPITCH];     dd[9] = v - p[-3 * FD_PPITCH - 1];  dd[10] = v - p[-2 * FD_PPITCH - 2]; dd[11] = v - p[-FD_PPITCH - 3];
-        dd[12] = v - p[-3];                dd[13] = v - p[FD_PPITCH - 3];      dd[14] = v - p[2 * FD_PPITCH - 2];  dd[15] = v - p[3 * FD_PPITCH - 1];
-        const int s = fast_strength(dd);
-        if (s > thr) sc[sj * FD_CW + si] = (uint8_t)(s - 1);
+    // ---- exact strength for the compacted candidates; the corners among them are compacted in place (entry n_corner +
+    //      rank never lies beyond the entries this pass has already read) ----
+    int n_corner = 0;                                                        // uniform
+    for (int base = 0; base < n_list; base += 64) {
+        const int c = base + lane;
+        int i = 0, s = 0;
+        if (c < n_list) {
+            i = list[c];
+            const int sj = i >> 6, si = i & 63;
+            const uint8_t* p = &pix[(sj + 3) * FD_PPITCH + 8 + si];
+            const int v = p[0];
+            int dd[16];
+            dd[0] = v - p[3 * FD_PPITCH];      dd[1] = v - p[3 * FD_PPITCH + 1];   dd[2] = v - p[2 * FD_PPITCH + 2];   dd[3] = v - p[FD_PPITCH + 3];
+            dd[4] = v - p[3];                  dd[5] = v - p[-FD_PPITCH + 3];      dd[6] = v - p[-2 * FD_PPITCH + 2];  dd[7] = v - p[-3 * FD_PPITCH + 1];
+            dd[8] = v - p[-3 * FD_PPITCH];     dd[9] = v - p[-3 * FD_PPITCH - 1];  dd[10] = v - p[-2 * FD_PPITCH - 2]; dd[11] = v - p[-FD_PPITCH - 3];
+            dd[12] = v - p[-3];                dd[13] = v - p[FD_PPITCH - 3];      dd[14] = v - p[2 * FD_PPITCH - 2];  dd[15] = v - p[3 * FD_PPITCH - 1];
+            s = fast_strength(dd);
+        }
+        const bool corner = s > thr;
+        const uint64_t b = __ballot(corner);
+        if (corner) {
+            sc[i] = (uint8_t)(s - 1);
+            list[n_corner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)i;
+        }
+        n_corner += __builtin_popcountll(b);
     }
-    __syncthreads();
+    fd_phase_fence();
 
-    // ---- strict 3x3 maxima of the output region (container rows 1..62, columns 2..61) -> per-cell candidate lists ----
+    // ---- strict 3x3 maxima of the output region (container rows 1..30, columns 2..61) -> per-cell candidate lists.
+    //      Only the listed corners have a score; the eight neighbours are read unconditionally so that the LDS reads of
+    //      one entry are in flight together instead of forming a chain of dependent, short-circuited tests. ----
     const int cells = G.ct_cols * G.ct_rows;
-#pragma unroll
-    for (int round = 0; round < FD_ROUNDS; round++) {
-        const int r = 1 + (t >> 4) + 16 * round;
-        if (r > FD_OH) continue;
-        const uint32_t S4 = *reinterpret_cast<const uint32_t*>(&sc[r * FD_CW + 4 * d]);
-        if (S4 == 0) continue;                       // a score of 0 can never be a strict maximum
-        for (int j = 0; j < 4; j++) {
-            const int s = (S4 >> (8 * j)) & 0xff, col = 4 * d + j;
-            if (s == 0 || col < 2 || col > FD_OW + 1) continue;
-            const uint8_t* q = &sc[r * FD_CW + col];
-            if (s > q[-1] && s > q[1] && s > q[-FD_CW - 1] && s > q[-FD_CW] && s > q[-FD_CW + 1] &&
-                s > q[FD_CW - 1] && s > q[FD_CW] && s > q[FD_CW + 1]) {
-                const int gx = CX0 + col, gy = OY - 1 + r;
-                const int cxi = fast_cell_of(gx, G.size_x, G.inv_x), cyi = fast_cell_of(gy, G.size_y, G.inv_y);
-                const int gcell = img_i * cells + cyi * G.ct_cols + cxi;
-                const int at = atomicAdd(&cand_count[gcell], 1);
-                if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
-            }
+    for (int c = lane; c < n_corner; c += 64) {
+        const int i = list[c];
+        const int r = i >> 6, col = i & 63;
+        const int s = sc[i];
+        if (s == 0 || r < 1 || r > FD_OH || col < 2 || col > FD_OW + 1) continue;
+        const uint8_t* q = &sc[i];
+        const int n0 = q[-FD_CW - 1], n1 = q[-FD_CW], n2 = q[-FD_CW + 1], n3 = q[-1], n4 = q[1], n5 = q[FD_CW - 1], n6 = q[FD_CW], n7 = q[FD_CW + 1];
+        const int top = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+        if (s > top) {
+            const int gx = CX0 + col, gy = OY - 1 + r;
+            const int cxi = fast_cell_of(gx, G.size_x, G.inv_x), cyi = fast_cell_of(gy, G.size_y, G.inv_y);
+            const int gcell = img_i * cells + cyi * G.ct_cols + cxi;
+            const int at = atomicAdd(&cand_count[(size_t)gcell * FAST_COUNT_STRIDE], 1);
+            if (at < G.cand_cap) cand[(uint64_t)gcell * G.cand_cap + at] = fast_key(s, gy - cyi * G.size_y, gx - cxi * G.size_x);
         }
     }
 }
@@ -272,7 +286,7 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32
     const int gcell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gcell >= total_cells) return;          // uniform for the wave
     const int cell = gcell % (G.ct_cols * G.ct_rows);
-    const int survivors = cand_count[gcell];
+    const int survivors = cand_count[(size_t)gcell * FAST_COUNT_STRIDE];
     const int n = min(survivors, G.cand_cap);
     const uint32_t* c = cand + (uint64_t)gcell * G.cand_cap;
     const int keep = min(n, G.per_cell);
@@ -302,7 +316,7 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32
     if (lane == 0) {   // after the wave's read of the counter above (program order within the wave)
         out_count[gcell] = keep;
         surv_count[gcell] = survivors;
-        cand_count[gcell] = 0;
+        cand_count[(size_t)gcell * FAST_COUNT_STRIDE] = 0;
     }
 }
 

@@ -22,4 +22,12 @@ for per in (1, 16):
         for _ in range(20): ctx.lk_track(jobs, prm)
         t = ctx.kernel_times(); ctx.profile(0)
         print(f"{npts:6d} points  {label:18s} {1e3 * t['lk_ms'] / t['lk_launches']:7.1f} us", flush=True)
+# points far outside the image: every level is skipped at once (launch + prologue + epilogue only)
+for per in (1, 16):
+    jobs = [dict(prev=(s, 0), next=(s, 1), prev_xy=np.full((per, 2), -900.0, np.float32)) for s in range(S)]
+    prm = D.LKParams(win=21, max_level=3)
+    ctx.lk_track(jobs, prm); ctx.profile(1); ctx.kernel_times()
+    for _ in range(20): ctx.lk_track(jobs, prm)
+    t = ctx.kernel_times(); ctx.profile(0)
+    print(f"{per * S:6d} points  all outside        {1e3 * t['lk_ms'] / t['lk_launches']:7.1f} us", flush=True)
 ctx.queue_time_begin(); print("empty event pair", 1e3 * ctx.queue_time_end(), "us")
