@@ -3,8 +3,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from feature_tracker_amd import device as D, synth
-if len(sys.argv) > 1:          # an experimental build of the device library
-    D.LIB_PATH = os.path.abspath(sys.argv[1])
+if os.environ.get("FT_EXP_LIB"):   # an experimental build of the device library
+    D.LIB_PATH = os.path.abspath(os.environ["FT_EXP_LIB"])
 S = 64
 w, h = 752, 480
 seqs = [synth.Sequence(w, h, 1, stream_id=s) for s in range(S)]

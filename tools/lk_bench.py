@@ -4,6 +4,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from feature_tracker_amd import device as D, synth
+if os.environ.get("FT_EXP_LIB"):   # an experimental build of the device library
+    D.LIB_PATH = os.path.abspath(os.environ["FT_EXP_LIB"])
 S = 64
 w, h = 752, 480
 seqs = [synth.Sequence(w, h, 2, stream_id=s) for s in range(S)]
@@ -23,8 +25,13 @@ def run(label, **kw):
     t = ctx.kernel_times()
     ctx.profile(False)
     print(f"{label:28s} {1e3 * t['lk_ms'] / t['lk_launches']:8.1f} us  ({npts} points)", flush=True)
+mode = sys.argv[1] if len(sys.argv) > 1 else ""
+if mode == "iter0":      # one parameter set only, for counter passes
+    run("max_iter=0", max_iter=0); sys.exit(0)
+if mode == "iter1":
+    run("max_iter=1", max_iter=1); sys.exit(0)
 run("full win21 L3")
-if len(sys.argv) > 1 and sys.argv[1] == "full":   # only the product configuration (for counter passes)
+if mode == "full":
     sys.exit(0)
 run("max_iter=1", max_iter=1)
 run("max_iter=0", max_iter=0)
