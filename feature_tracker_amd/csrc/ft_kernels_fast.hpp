@@ -89,6 +89,7 @@ constexpr int FD_PPITCH = 80;                    // pixel tile row: columns CX0-
 constexpr int FD_PROWS = FD_CH + 6;              // rows OY-4 .. OY+33
 constexpr int FD_GROUPS = FD_PPITCH / 8;         // 8-byte groups per pixel row
 constexpr int FD_LIST = FD_CW * FD_CH;           // candidate list capacity
+constexpr int FD_ENTRIES_AT = FD_LIST - FD_LIST / 4;   // one task entry per four pixels, kept in the list's last quarter
 
 struct __attribute__((packed)) FdU2Unaligned { uint32_t a, b; };
 
@@ -99,6 +100,17 @@ __host__ __device__ inline int fast_tiles_y(int h) { return (h + FD_OH - 1) / FD
 __device__ __forceinline__ void fd_phase_fence() {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
+}
+
+// inclusive prefix sum over the 64 lanes (row_shr 1, 2, 3 within quads of the row scan, then the row broadcasts)
+__device__ __forceinline__ int fd_wave_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2, 3
+    return v;
 }
 
 // Fused detector: the pixel tile is staged in LDS once; a cheap compass test on four pixels per lane compacts the
@@ -129,6 +141,18 @@ __global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L,
     {
         constexpr int SR = (FD_PROWS * FD_GROUPS + 63) / 64;
         uint2 v[SR];
+        // most tiles: every staged byte is an image byte (wave-uniform), so no clamps and no row-end cases
+        const bool interior = CX0 >= 8 && CX0 - 8 + FD_PPITCH <= G.w && OY >= 4 && OY - 4 + FD_PROWS <= G.h;
+        if (interior) {
+            const uint32_t origin = (uint32_t)(OY - 4) * pitch + (uint32_t)(CX0 - 8);
+#pragma unroll
+            for (int k = 0; k < SR; k++) {
+                const int g = min(lane + 64 * k, FD_PROWS * FD_GROUPS - 1);
+                const int row = g / FD_GROUPS, c8 = g - row * FD_GROUPS;
+                const FdU2Unaligned u = *reinterpret_cast<const FdU2Unaligned*>(img + (origin + (uint32_t)row * pitch + 8u * (uint32_t)c8));
+                v[k] = make_uint2(u.a, u.b);
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < SR; k++) {
             const int g = min(lane + 64 * k, FD_PROWS * FD_GROUPS - 1);
@@ -179,7 +203,7 @@ __global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L,
     const int d = lane & 15;                                                 // container dword column of this lane
     const uint32_t colbytes = *reinterpret_cast<const uint32_t*>(&col_ok[4 * d]);   // one byte per column
     const uint32_t colbits = (colbytes & 1u) | ((colbytes >> 7) & 2u) | ((colbytes >> 14) & 4u) | ((colbytes >> 21) & 8u);
-    int n_list = 0;                                                          // uniform: entries in the candidate list
+    int n_ent = 0;                                                           // uniform: task entries so far
 #pragma unroll
     for (int round = 0; round < FD_ROUNDS; round++) {
         const int r = (lane >> 4) + 4 * round;                               // container row
@@ -196,21 +220,42 @@ __global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L,
             const uint32_t m23 = fast_compass2(__builtin_amdgcn_perm(0u, C, 0x0c030c02u), __builtin_amdgcn_perm(0u, N, 0x0c030c02u),
                                                __builtin_amdgcn_perm(0u, S, 0x0c030c02u), __builtin_amdgcn_perm(C, Wd, 0x0c040c03u),
                                                __builtin_amdgcn_perm(Ed, C, 0x0c060c05u), thr2);      // pixels x+2, x+3: W = x-1, x; E = x+5, x+6
-            hits = ((m01 & 0xffffu) ? 1u : 0u) | ((m01 >> 16) ? 2u : 0u) | ((m23 & 0xffffu) ? 4u : 0u) | ((m23 >> 16) ? 8u : 0u);
-            hits &= colbits;
+            // non-zero halves -> bits 0 and 16 (packed minimum with 1), then the four bits side by side
+            // (as an assembly statement: the compiler rewrites min(x, 1) into four compares, four selects and two permutes)
+            uint32_t h01, h23;
+            asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(h01) : "v"(m01));
+            asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(h23) : "v"(m23));
+            const uint32_t h = h01 | (h23 << 2);                             // bits 0, 2, 16, 18
+            hits = (h | (h >> 15)) & colbits;                                // bits 0..3: pixels x .. x+3
         }
-        // Compaction without atomics (the list belongs to this wavefront): the round's entries are laid out by pixel
-        // position within the task (all first pixels, then all second pixels, ...), each group ranked with a ballot.
-        if (__ballot(hits != 0u) != 0ull) {
-            const uint64_t b0 = __ballot(hits & 1u), b1 = __ballot(hits & 2u), b2 = __ballot(hits & 4u), b3 = __ballot(hits & 8u);
-            const int n0 = __builtin_popcountll(b0), n1 = __builtin_popcountll(b1), n2 = __builtin_popcountll(b2), n3 = __builtin_popcountll(b3);
-            const uint16_t key = (uint16_t)((r << 6) | (4 * d));
-            if (hits & 1u) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))] = key;
-            if (hits & 2u) list[n_list + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))] = key | 1;
-            if (hits & 4u) list[n_list + n0 + n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u))] = key | 2;
-            if (hits & 8u) list[n_list + n0 + n1 + n2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, 0u))] = key | 3;
-            n_list += n0 + n1 + n2 + n3;
+        // Compaction without atomics (the list belongs to this wavefront), first by task: one entry (row, dword column,
+        // hit bits) per lane that has a hit, ranked with one ballot.  The entries live in the last quarter of the list.
+        const uint64_t b = __ballot(hits != 0u);
+        if (b != 0ull) {
+            if (hits != 0u)
+                list[FD_ENTRIES_AT + n_ent + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] =
+                    (uint16_t)((r << 8) | (d << 4) | (int)hits);
+            n_ent += __builtin_popcountll(b);
         }
+    }
+    fd_phase_fence();
+
+    // ---- entries -> one list element per candidate pixel (dense lanes for the strength pass).  A batch of 64 entries
+    //      writes at most 256 elements from 256 * batch on, which never reaches an entry that is still to be read
+    //      (the entries of batch j start at FD_ENTRIES_AT + 64 j = 1536 + 64 j). ----
+    int n_list = 0;                                                          // uniform: elements in the candidate list
+    for (int base = 0; base < n_ent; base += 64) {
+        const int e = base + lane < n_ent ? (int)list[FD_ENTRIES_AT + base + lane] : 0;
+        const int h = e & 15;
+        const int cnt = __builtin_popcount((unsigned)h);
+        const int incl = fd_wave_scan(cnt);                                  // inclusive prefix sum over the lanes
+        int at = n_list + incl - cnt;
+        const int key = ((e >> 8) << 6) | (((e >> 4) & 15) << 2);            // row, first pixel column
+        if (h & 1) list[at++] = (uint16_t)key;
+        if (h & 2) list[at++] = (uint16_t)(key | 1);
+        if (h & 4) list[at++] = (uint16_t)(key | 2);
+        if (h & 8) list[at] = (uint16_t)(key | 3);
+        n_list += __builtin_amdgcn_readlane(incl, 63);
     }
     fd_phase_fence();
 
