@@ -246,10 +246,12 @@ int sync_and_deliver(ft_ctx* c) {
     return deliver_pending(c, ~0ull);
 }
 
-void launch_reject(ft_ctx* c, const OutlierArgs& o, int n_jobs) {
+// max_points: the largest job of the launch
+void launch_reject(ft_ctx* c, const OutlierArgs& o, int n_jobs, int max_points) {
     EventPair ep;
     prof_begin(c, 3, ep);
-    hipLaunchKernelGGL(ransac_kernel, dim3(n_jobs), dim3(256), 0, c->q, o);
+    if (max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(n_jobs), dim3(512), 0, c->q, o);   // 512: the most that leaves the hypothesis phase its 193 registers
+    else hipLaunchKernelGGL(ransac_kernel<256>, dim3(n_jobs), dim3(256), 0, c->q, o);
     prof_end(c, ep);
 }
 
@@ -796,7 +798,9 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         o.out_status = c->lk_out_host_dev + 12 * N;
         o.hypotheses = prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 256;
         o.seed = prm->ransac_seed;
-        launch_reject(c, o, n_jobs);
+        int max_points = 0;
+        for (int j = 0; j < n_jobs; j++) max_points = std::max(max_points, jobs[j].n);
+        launch_reject(c, o, n_jobs, max_points);
         FT_HIP(c, hipGetLastError());
         if (want_iters)
             FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
@@ -865,7 +869,9 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
     o.out_status = c->lk_out_host_dev + 12 * N;
     o.hypotheses = hypotheses > 0 ? hypotheses : 256;
     o.seed = seed;
-    launch_reject(c, o, n_sets);
+    int max_points = 0;
+    for (int j = 0; j < n_sets; j++) max_points = std::max(max_points, sets[j].n);
+    launch_reject(c, o, n_sets, max_points);
     FT_HIP(c, hipGetLastError());
     PendingLK& P = c->lk_pending;
     P.jobs = std::move(deliver);

@@ -103,7 +103,11 @@ __device__ inline int ro_hypotheses_needed(int inliers, int n, int max_h) {
     ((j) == 8 ? (v)[8] : (j) == 7 ? (v)[7] : (j) == 6 ? (v)[6] : (j) == 5 ? (v)[5] : (j) == 4 ? (v)[4] : (j) == 3 ? (v)[3] \
      : (j) == 2 ? (v)[2] : (j) == 1 ? (v)[1] : (v)[0])
 
-__global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
+// T threads per workgroup: 256 (the usual job of a few hundred points: the latency of the dependent phases dominates)
+// or 512 (jobs of thousands of points, where the per-point phases dominate).  Hypotheses are always built by the first
+// 256 threads; everything per point is shared by all T.  The result does not depend on T.
+template <int T>
+__global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
     __shared__ float4 nl[RO_NORM_LDS];
     __shared__ double Fs[RO_HYP_PER_WG][9];
     __shared__ double best_F[9];
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
     const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
 
     // ---- normalized coordinates of both point sets ----
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += T) {
         const float2 p = ro_undistort(a.prev_xy[2 * (first + i)], a.prev_xy[2 * (first + i) + 1], c0);
         const float2 q = ro_undistort(a.next_xy[2 * (first + i)], a.next_xy[2 * (first + i) + 1], c1);
         const float4 m = make_float4(p.x, p.y, q.x, q.y);
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
     for (int h0 = 0; h0 < s_stop; h0 += RO_HYP_PER_WG) {   // s_stop only changes between the barriers at the loop's end
         if (t < RO_HYP_PER_WG) cnt[t] = 0;
         // ---- one hypothesis per eight lanes, lane r holds equation r ----
-        {
+        if (T == 256 || t < 256) {   // whole wavefronts either way
             const int r = t & 7, hl = t >> 3, h = h0 + hl;
             const int gbase = (t & 63) & ~7;
             int mine = 0;
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
 #pragma unroll
                     for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
                     int c = 0;
-                    for (int i = slice; i < n; i += 256 / RO_SUB) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
+                    for (int i = slice; i < n; i += T / RO_SUB) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
                     if (c) atomicAdd(&cnt[hh], c);
                 }
             }
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(256) ransac_kernel(OutlierArgs a) {
 
     // ---- final mask and the batch results into the pinned host block ----
     const bool have_model = s_have != 0;
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += T) {
         const int g = first + i;
         const bool keep = have_model && a.status[g] && ro_inlier(best_F, i < RO_NORM_LDS ? nl[i] : a.norm[g], thr2);
         a.out_xy[2 * g] = a.next_xy[2 * g];
