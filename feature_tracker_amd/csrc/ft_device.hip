@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -70,7 +71,15 @@ struct ft_ctx {
     // tracking queue, a high-priority queue that waits for an event of a normal-priority queue can starve that queue
     // and hang the device.  With equal priorities the kernels only slow each other down (they are bound by vector
     // issue, not by latency) and the event traffic costs host time: 0.160 -> 0.178 ms per step with two stream groups.
-    hipStream_t q = nullptr;
+    hipStream_t q_ = nullptr;            // use enq(ctx) to put work on it
+    // Completion flag of the outlier-rejection kernel: its last workgroup stores a sequence number to pinned host
+    // memory, and a fence taken while that launch is the newest work on the queue is waited for by polling the flag
+    // (about 5 us sooner than through an event).
+    unsigned* done_count_dev = nullptr;  // device: workgroups of the launch that have finished
+    unsigned* done_flag_host = nullptr;  // pinned
+    unsigned* done_flag_dev = nullptr;   // its device address
+    uint32_t done_seq = 0;               // last sequence number handed to a launch
+    uint32_t tail_flag_seq = 0;          // != 0: the newest work on the queue is the launch that stores this number
     ArenaDesc arena{};
     int lvl_w[FT_MAX_LEVELS]{}, lvl_h[FT_MAX_LEVELS]{};   // geometry of the largest frame
     std::vector<SlotState> slots;
@@ -111,7 +120,7 @@ struct ft_ctx {
     // every *_async call takes the next sequence number; a fence remembers the number reached when it was recorded
     uint64_t seq = 0;
     static constexpr int FENCE_RING = 16;
-    struct Fence { hipEvent_t ev = nullptr; uint64_t id = 0, seq = 0; };
+    struct Fence { hipEvent_t ev = nullptr; uint64_t id = 0, seq = 0; uint32_t flag_seq = 0; };
     Fence fences[FENCE_RING];
     uint64_t fence_ids = 0;
 
@@ -130,6 +139,12 @@ struct ft_ctx {
 };
 
 namespace {
+
+// the context's queue, for putting work on it: whatever is enqueued next is then the newest work on the queue
+inline hipStream_t enq(ft_ctx* c) {
+    c->tail_flag_seq = 0;
+    return c->q_;
+}
 
 #define FT_HIP(ctx, call)                                                                          \
     do {                                                                                           \
@@ -151,11 +166,11 @@ void prof_begin(ft_ctx* c, int kind, EventPair& ep) {
     if (!c->ev_pool.empty()) { ep = c->ev_pool.back(); c->ev_pool.pop_back(); }
     else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
     ep.kind = kind;
-    (void)hipEventRecord(ep.a, c->q);
+    (void)hipEventRecord(ep.a, enq(c));
 }
 void prof_end(ft_ctx* c, EventPair& ep) {
     if (!(c->profile & 1) || !ep.a) return;
-    (void)hipEventRecord(ep.b, c->q);
+    (void)hipEventRecord(ep.b, enq(c));
     c->ev_inflight.push_back(ep);
 }
 void prof_collect(ft_ctx* c) {
@@ -239,7 +254,7 @@ int deliver_pending(ft_ctx* c, uint64_t upto) {
 }
 
 int sync_and_deliver(ft_ctx* c) {
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     std::fill(c->stage_busy.begin(), c->stage_busy.end(), 0);
     std::fill(c->stage_batch_idx.begin(), c->stage_batch_idx.end(), -1);
     prof_collect(c);
@@ -247,12 +262,15 @@ int sync_and_deliver(ft_ctx* c) {
 }
 
 // max_points: the largest job of the launch
-void launch_reject(ft_ctx* c, const OutlierArgs& o, int n_jobs, int max_points) {
+void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, int max_points) {
     EventPair ep;
     prof_begin(c, 3, ep);
-    if (max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(n_jobs), dim3(512), 0, c->q, o);   // 512: the most that leaves the hypothesis phase its 193 registers
-    else hipLaunchKernelGGL(ransac_kernel<256>, dim3(n_jobs), dim3(256), 0, c->q, o);
+    const uint32_t seq = ++c->done_seq ? c->done_seq : ++c->done_seq;   // never 0
+    o.done_count = c->done_count_dev; o.done_flag = c->done_flag_dev; o.done_seq = seq;
+    if (max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(n_jobs), dim3(512), 0, enq(c), o);   // 512: the most that leaves the hypothesis phase its 193 registers
+    else hipLaunchKernelGGL(ransac_kernel<256>, dim3(n_jobs), dim3(256), 0, enq(c), o);
     prof_end(c, ep);
+    if (!(c->profile & 1)) c->tail_flag_seq = seq;   // (with timing on, an event record follows the launch)
 }
 
 int pick_seglen(int win_w, int win_h) {
@@ -290,7 +308,7 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
         const int do_grad = grad ? 1 : 0;
         if (l >= from_level && (do_down || do_grad)) {
             const int tiles = ((lw + LV_TX - 1) / LV_TX) * ((lh + LV_TY - 1) / LV_TY);
-            hipLaunchKernelGGL((level_kernel<false>), dim3(xcd_grid(tiles * L.n)), dim3(256), 0, c->q, c->arena, L, none, 0, l, lw, lh,
+            hipLaunchKernelGGL((level_kernel<false>), dim3(xcd_grid(tiles * L.n)), dim3(256), 0, enq(c), c->arena, L, none, 0, l, lw, lh,
                                (uint64_t)0, do_grad, do_down);
         }
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
@@ -318,8 +336,8 @@ static int stage_rows(ft_ctx* c, int si, const uint8_t* host, int w, int h, size
 
 template <int SEGLEN>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
-    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(64), 0, c->q, a);
-    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(64), 0, c->q, a);
+    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
 }
 
 }  // namespace
@@ -362,7 +380,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lim = *lim;
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);
-    if (hipStreamCreateWithFlags(&c->q, hipStreamNonBlocking) != hipSuccess) return fail(FT_E_HIP);
+    if (hipStreamCreateWithFlags(&c->q_, hipStreamNonBlocking) != hipSuccess) return fail(FT_E_HIP);
 
     // arena layout from the largest frame
     size_t off = 0;
@@ -423,6 +441,14 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lk_out_dev = (uint8_t*)p;
     if (hipMalloc(&p, sizeof(float4) * N) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_norm_dev = (float4*)p;
+    if (hipMalloc(&p, 256) != hipSuccess) return fail(FT_E_NOMEM);
+    c->done_count_dev = (unsigned*)p;
+    if (hipMemset(c->done_count_dev, 0, 256) != hipSuccess) return fail(FT_E_HIP);
+    if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
+    c->done_flag_host = (unsigned*)p;
+    *c->done_flag_host = 0;
+    if (hipHostGetDevicePointer(&p, c->done_flag_host, 0) != hipSuccess) return fail(FT_E_HIP);
+    c->done_flag_dev = (unsigned*)p;
 
     // FAST scratch
     c->cand_entries_per_img = ((size_t)lim->max_width + 2 * 64) * ((size_t)lim->max_height + 2 * 64) / 4 + (size_t)lim->max_grid_cells;
@@ -458,7 +484,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
 void ft_ctx_destroy(ft_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->q) (void)hipStreamSynchronize(c->q);
+    if (enq(c)) (void)hipStreamSynchronize(enq(c));
     for (auto& e : c->stage_done) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->stage_batch_ev) if (e) (void)hipEventDestroy(e);
     for (auto& ep : c->ev_inflight) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -472,6 +498,8 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
+    if (c->done_count_dev) (void)hipFree(c->done_count_dev);
+    if (c->done_flag_host) (void)hipHostFree(c->done_flag_host);
     if (c->match_dev) (void)hipFree(c->match_dev);
     if (c->match_host) (void)hipHostFree(c->match_host);
     if (c->cand) (void)hipFree(c->cand);
@@ -480,7 +508,7 @@ void ft_ctx_destroy(ft_ctx* c) {
     for (auto& f : c->fences) if (f.ev) (void)hipEventDestroy(f.ev);
     if (c->pf_dev) (void)hipFree(c->pf_dev);
     if (c->pf_host) (void)hipHostFree(c->pf_host);
-    if (c->q) (void)hipStreamDestroy(c->q);
+    if (enq(c)) (void)hipStreamDestroy(enq(c));
     delete c;
 }
 
@@ -493,8 +521,8 @@ int ft_upload(ft_ctx* c, int stream, int slot, const uint8_t* host, int w, int h
     { const int rc = stage_rows(c, si, host, w, h, stride); if (rc) return rc; }
     uint8_t* st = c->stage + (size_t)si * c->stage_bytes_per_slot;
     uint8_t* dst = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[0].img_off;
-    FT_HIP(c, hipMemcpy2DAsync(dst, c->arena.lv[0].img_pitch, st, (size_t)w, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->q));
-    FT_HIP(c, hipEventRecord(c->stage_done[si], c->q));
+    FT_HIP(c, hipMemcpy2DAsync(dst, c->arena.lv[0].img_pitch, st, (size_t)w, (size_t)w, (size_t)h, hipMemcpyHostToDevice, enq(c)));
+    FT_HIP(c, hipEventRecord(c->stage_done[si], enq(c)));
     c->stage_busy[si] = 1;
     c->slots[si] = SlotState{w, h, 1, 0};
     return FT_OK;
@@ -516,7 +544,7 @@ int ft_set_frames_device(ft_ctx* c, int n, const int* streams, const int* slots,
         FramePtrs F;
         for (int i = 0; i < m; i++) F.p[i] = static_cast<const uint8_t*>(dev[first + i]);
         dim3 grid(((w + 15) / 16 + 255) / 256, h, m);
-        hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, c->q, c->arena, L, F, first, w, h, (uint64_t)stride);
+        hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, enq(c), c->arena, L, F, first, w, h, (uint64_t)stride);
     }
     FT_HIP(c, hipGetLastError());
     for (int i = 0; i < n; i++) c->slots[L.idx[i]] = SlotState{w, h, 1, 0};
@@ -560,7 +588,7 @@ static int frames_to_pyramid(ft_ctx* c, const ImgList& L, int n, const uint8_t* 
         const int m = std::min(FRAME_PTRS, n - first);
         FramePtrs F{};
         for (int i = 0; i < m; i++) F.p[i] = src[first + i];
-        hipLaunchKernelGGL((level_kernel<true>), dim3(xcd_grid(tiles * m)), dim3(256), 0, c->q, c->arena, L, F, first, 0, w, h,
+        hipLaunchKernelGGL((level_kernel<true>), dim3(xcd_grid(tiles * m)), dim3(256), 0, enq(c), c->arena, L, F, first, 0, w, h,
                            (uint64_t)stride, 0, top > 0 ? 1 : 0);
     }
     FT_HIP(c, hipGetLastError());
@@ -622,7 +650,7 @@ int ft_set_frames_staged_pyramid(ft_ctx* c, int n, const int* streams, const int
     // the staging buffers are free again once the level-0 pass has read them
     const int e = c->stage_batch_next;
     c->stage_batch_next = (e + 1) % ft_ctx::STAGE_EV_RING;
-    FT_HIP(c, hipEventRecord(c->stage_batch_ev[e], c->q));
+    FT_HIP(c, hipEventRecord(c->stage_batch_ev[e], enq(c)));
     for (int i = 0; i < n; i++) c->stage_batch_idx[L.idx[i]] = e;
     return FT_OK;
 }
@@ -721,7 +749,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     const uint8_t* ib = direct_in ? c->lk_in_host_dev : c->lk_in_dev;
     if (!direct_in) {
         const int n16 = (int)((off_next + 8 * N + 15) / 16);
-        hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->q, reinterpret_cast<const uint4*>(c->lk_in_host_dev),
+        hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, enq(c), reinterpret_cast<const uint4*>(c->lk_in_host_dev),
                            reinterpret_cast<uint4*>(c->lk_in_dev), n16);
     }
 
@@ -741,7 +769,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         sa.next_xy = reinterpret_cast<float*>(c->lk_in_dev + off_next);
         sa.err = nullptr; sa.status = nullptr; sa.out_xy = nullptr; sa.out_err = nullptr; sa.out_status = nullptr;
         sa.total = (int)N; sa.emit = 0; sa.threshold = prm->stereo_threshold;
-        hipLaunchKernelGGL(stereo_seed_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->q, sa);
+        hipLaunchKernelGGL(stereo_seed_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, enq(c), sa);
     }
     a.next_xy = reinterpret_cast<float*>(ob);
     a.err = reinterpret_cast<float*>(ob + 8 * N);
@@ -760,7 +788,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     const double eps = std::min(std::max(prm->eps, 0.), 10.);
     a.epsilon = eps * eps;
     a.min_eig = prm->min_eig;
-    if (want_iters) FT_HIP(c, hipMemsetAsync(a.iters, 0xff, sizeof(int) * N * nlev, c->q));
+    if (want_iters) FT_HIP(c, hipMemsetAsync(a.iters, 0xff, sizeof(int) * N * nlev, enq(c)));
 
     EventPair ep;
     prof_begin(c, 1, ep);
@@ -782,10 +810,10 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         sa.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);
         sa.out_status = c->lk_out_host_dev + 12 * N;
         sa.emit = reject ? 0 : 1;
-        hipLaunchKernelGGL(stereo_check_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->q, sa);
+        hipLaunchKernelGGL(stereo_check_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, enq(c), sa);
         FT_HIP(c, hipGetLastError());
         if (!reject && want_iters)
-            FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
+            FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, enq(c)));
     }
     if (reject) {
         // final mask on the device; the kernel also moves positions, residuals and status into the pinned host block
@@ -803,10 +831,10 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         launch_reject(c, o, n_jobs, max_points);
         FT_HIP(c, hipGetLastError());
         if (want_iters)
-            FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, c->q));
+            FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, enq(c)));
     } else if (!direct_out && !stereo) {
         const size_t out_bytes = align_up(13 * N, 16) + (want_iters ? sizeof(int) * N * nlev : 0);
-        FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, c->q));
+        FT_HIP(c, hipMemcpyAsync(c->lk_out_host, ob, out_bytes, hipMemcpyDeviceToHost, enq(c)));
     }
 
     PendingLK& P = c->lk_pending;
@@ -855,7 +883,7 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
         off += (size_t)S.n;
     }
     const int n16 = (int)((off_next + 8 * N + 15) / 16);
-    hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->q, reinterpret_cast<const uint4*>(c->lk_in_host_dev),
+    hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, enq(c), reinterpret_cast<const uint4*>(c->lk_in_host_dev),
                        reinterpret_cast<uint4*>(c->lk_in_dev), n16);
     OutlierArgs o;
     o.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
@@ -931,8 +959,8 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     EventPair ep;
     prof_begin(c, 2, ep);
     const int tiles = fast_tiles_x(w) * fast_tiles_y(h);
-    hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(64), 0, c->q, c->arena, L, G, c->cand, c->cand_count);
-    hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, c->q, G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
+    hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(64), 0, enq(c), c->arena, L, G, c->cand, c->cand_count);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
     prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
     // cand is indexed [image*cells + cell][cand_cap], the keypoints [image*cells + cell][per_cell]
@@ -969,7 +997,7 @@ void ft_homography(const float* K4, const float* R, float* H) {
 // descriptor staging (device + pinned host, 80 bytes per descriptor of capacity), grown on demand
 static int ensure_match_cap(ft_ctx* c, size_t need) {
     if (need <= c->match_cap) return FT_OK;
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     if (c->match_dev) (void)hipFree(c->match_dev);
     if (c->match_host) (void)hipHostFree(c->match_host);
     c->match_dev = nullptr; c->match_host = nullptr; c->match_cap = 0;
@@ -995,12 +1023,12 @@ int ft_compute_descriptors(ft_ctx* c, int stream, int slot, const float* xy, int
     // layout of both blocks: positions (8 n), descriptors (32 n), valid flags (n)
     const size_t off_desc = align_up(8 * (size_t)n, 256), off_valid = off_desc + 32 * (size_t)n;
     memcpy(c->match_host, xy, 8 * (size_t)n);
-    FT_HIP(c, hipMemcpyAsync(c->match_dev, c->match_host, 8 * (size_t)n, hipMemcpyHostToDevice, c->q));
-    hipLaunchKernelGGL(brief_kernel, dim3(n), dim3(64), 0, c->q, c->arena, si, c->slots[si].w, c->slots[si].h,
+    FT_HIP(c, hipMemcpyAsync(c->match_dev, c->match_host, 8 * (size_t)n, hipMemcpyHostToDevice, enq(c)));
+    hipLaunchKernelGGL(brief_kernel, dim3(n), dim3(64), 0, enq(c), c->arena, si, c->slots[si].w, c->slots[si].h,
                        reinterpret_cast<const float*>(c->match_dev), n, c->match_dev + off_desc, c->match_dev + off_valid);
     FT_HIP(c, hipGetLastError());
-    FT_HIP(c, hipMemcpyAsync(c->match_host + off_desc, c->match_dev + off_desc, 33 * (size_t)n, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipMemcpyAsync(c->match_host + off_desc, c->match_dev + off_desc, 33 * (size_t)n, hipMemcpyDeviceToHost, enq(c)));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     memcpy(desc, c->match_host + off_desc, 32 * (size_t)n);
     memcpy(valid, c->match_host + off_valid, (size_t)n);
     return FT_OK;
@@ -1018,16 +1046,16 @@ int ft_match_descriptors(ft_ctx* c, const uint8_t* desc0, int n0, const uint8_t*
     const size_t off_d1 = 32 * M, off_b0 = 64 * M, off_b1 = 72 * M;
     memcpy(c->match_host, desc0, 32 * (size_t)n0);
     memcpy(c->match_host + off_d1, desc1, 32 * (size_t)n1);
-    FT_HIP(c, hipMemcpyAsync(c->match_dev, c->match_host, 32 * (size_t)n0, hipMemcpyHostToDevice, c->q));
-    FT_HIP(c, hipMemcpyAsync(c->match_dev + off_d1, c->match_host + off_d1, 32 * (size_t)n1, hipMemcpyHostToDevice, c->q));
+    FT_HIP(c, hipMemcpyAsync(c->match_dev, c->match_host, 32 * (size_t)n0, hipMemcpyHostToDevice, enq(c)));
+    FT_HIP(c, hipMemcpyAsync(c->match_dev + off_d1, c->match_host + off_d1, 32 * (size_t)n1, hipMemcpyHostToDevice, enq(c)));
     const uint4* d0 = reinterpret_cast<const uint4*>(c->match_dev);
     const uint4* d1 = reinterpret_cast<const uint4*>(c->match_dev + off_d1);
-    hipLaunchKernelGGL(hamming_knn2_kernel, dim3((n0 + 3) / 4), dim3(256), 0, c->q, d0, n0, d1, n1, reinterpret_cast<uint2*>(c->match_dev + off_b0));
-    hipLaunchKernelGGL(hamming_knn2_kernel, dim3((n1 + 3) / 4), dim3(256), 0, c->q, d1, n1, d0, n0, reinterpret_cast<uint2*>(c->match_dev + off_b1));
+    hipLaunchKernelGGL(hamming_knn2_kernel, dim3((n0 + 3) / 4), dim3(256), 0, enq(c), d0, n0, d1, n1, reinterpret_cast<uint2*>(c->match_dev + off_b0));
+    hipLaunchKernelGGL(hamming_knn2_kernel, dim3((n1 + 3) / 4), dim3(256), 0, enq(c), d1, n1, d0, n0, reinterpret_cast<uint2*>(c->match_dev + off_b1));
     FT_HIP(c, hipGetLastError());
-    FT_HIP(c, hipMemcpyAsync(c->match_host + off_b0, c->match_dev + off_b0, 8 * (size_t)n0, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipMemcpyAsync(c->match_host + off_b1, c->match_dev + off_b1, 8 * (size_t)n1, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipMemcpyAsync(c->match_host + off_b0, c->match_dev + off_b0, 8 * (size_t)n0, hipMemcpyDeviceToHost, enq(c)));
+    FT_HIP(c, hipMemcpyAsync(c->match_host + off_b1, c->match_dev + off_b1, 8 * (size_t)n1, hipMemcpyDeviceToHost, enq(c)));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     // ratio and symmetry tests: O(n) on the host (TrackDescriptor.cpp:309-354)
     const uint2* b0 = reinterpret_cast<const uint2*>(c->match_host + off_b0);
     const uint2* b1 = reinterpret_cast<const uint2*>(c->match_host + off_b1);
@@ -1055,13 +1083,13 @@ int ft_predict_flow(ft_ctx* c, const float* H, const float* xy, float* xy_out, i
     FT_HIP(c, hipSetDevice(c->device));
     memcpy(c->pf_host, H, sizeof(float) * 9);
     memcpy(c->pf_host + 16, xy, sizeof(float) * 2 * (size_t)n);
-    FT_HIP(c, hipMemcpyAsync(c->pf_dev, c->pf_host, sizeof(float) * (16 + 2 * (size_t)n), hipMemcpyHostToDevice, c->q));
+    FT_HIP(c, hipMemcpyAsync(c->pf_dev, c->pf_host, sizeof(float) * (16 + 2 * (size_t)n), hipMemcpyHostToDevice, enq(c)));
     float* out_dev = c->pf_dev + 16 + 2 * c->pf_points;
-    hipLaunchKernelGGL(predict_flow_kernel, dim3((n + 255) / 256), dim3(256), 0, c->q, c->pf_dev, c->pf_dev + 16, out_dev, n);
+    hipLaunchKernelGGL(predict_flow_kernel, dim3((n + 255) / 256), dim3(256), 0, enq(c), c->pf_dev, c->pf_dev + 16, out_dev, n);
     FT_HIP(c, hipGetLastError());
     float* out_host = c->pf_host + 16 + 2 * c->pf_points;
-    FT_HIP(c, hipMemcpyAsync(out_host, out_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipMemcpyAsync(out_host, out_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, enq(c)));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     memcpy(xy_out, out_host, sizeof(float) * 2 * (size_t)n);
     return FT_OK;
 }
@@ -1087,8 +1115,8 @@ int ft_download_level(ft_ctx* c, int stream, int slot, int level, uint8_t* host,
     const int si = slot_index(c, stream, slot);
     FT_HIP(c, hipSetDevice(c->device));
     const uint8_t* src = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[level].img_off;
-    FT_HIP(c, hipMemcpy2DAsync(host, stride, src, c->arena.lv[level].img_pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipMemcpy2DAsync(host, stride, src, c->arena.lv[level].img_pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, enq(c)));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     return FT_OK;
 }
 
@@ -1101,8 +1129,8 @@ int ft_download_grad(ft_ctx* c, int stream, int slot, int level, int16_t* host, 
     if (level >= c->slots[si].grad_levels) return FT_E_STATE;
     FT_HIP(c, hipSetDevice(c->device));
     const uint8_t* src = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[level].grad_off;
-    FT_HIP(c, hipMemcpy2DAsync(host, stride_shorts * 2, src, c->arena.lv[level].grad_pitch, (size_t)w * 4, (size_t)h, hipMemcpyDeviceToHost, c->q));
-    FT_HIP(c, hipStreamSynchronize(c->q));
+    FT_HIP(c, hipMemcpy2DAsync(host, stride_shorts * 2, src, c->arena.lv[level].grad_pitch, (size_t)w * 4, (size_t)h, hipMemcpyDeviceToHost, enq(c)));
+    FT_HIP(c, hipStreamSynchronize(enq(c)));
     return FT_OK;
 }
 
@@ -1117,7 +1145,8 @@ int ft_fence(ft_ctx* c, uint64_t* token) {
     FT_HIP(c, hipSetDevice(c->device));
     const uint64_t id = ++c->fence_ids;
     ft_ctx::Fence& f = c->fences[id % ft_ctx::FENCE_RING];
-    FT_HIP(c, hipEventRecord(f.ev, c->q));
+    f.flag_seq = c->tail_flag_seq;   // the queue ends with a launch that reports its own completion
+    FT_HIP(c, hipEventRecord(f.ev, c->q_));
     f.id = id;
     f.seq = c->seq;
     *token = id;
@@ -1129,7 +1158,18 @@ int ft_wait(ft_ctx* c, uint64_t token) {
     ft_ctx::Fence& f = c->fences[token % ft_ctx::FENCE_RING];
     if (token == 0 || f.id != token) return FT_E_INVALID;   // never issued, or its ring entry was reused
     FT_HIP(c, hipSetDevice(c->device));
-    FT_HIP(c, hipEventSynchronize(f.ev));
+    bool done = false;
+    if (f.flag_seq) {
+        // poll the kernel's own completion flag; give up after a while and take the event (which covers the same work)
+        const volatile unsigned* flag = c->done_flag_host;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !done; spins++) {
+            done = (int32_t)(*flag - f.flag_seq) >= 0;
+            if (!done && (spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!done) FT_HIP(c, hipEventSynchronize(f.ev));
     prof_collect(c);
     return deliver_pending(c, f.seq);
 }
@@ -1153,14 +1193,14 @@ int ft_kernel_times(ft_ctx* c, ft_kernel_time* out, int reset) {
 int ft_queue_time_begin(ft_ctx* c) {
     if (!c) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
-    FT_HIP(c, hipEventRecord(c->region_a, c->q));
+    FT_HIP(c, hipEventRecord(c->region_a, enq(c)));
     return FT_OK;
 }
 
 int ft_queue_time_end(ft_ctx* c, float* ms) {
     if (!c || !ms) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
-    FT_HIP(c, hipEventRecord(c->region_b, c->q));
+    FT_HIP(c, hipEventRecord(c->region_b, enq(c)));
     FT_HIP(c, hipEventSynchronize(c->region_b));
     FT_HIP(c, hipEventElapsedTime(ms, c->region_a, c->region_b));
     return FT_OK;

@@ -33,6 +33,10 @@ struct OutlierArgs {
     uint8_t* out_status;       // pinned host
     int hypotheses;            // <= 256
     uint32_t seed;
+    // completion flag (optional): the last workgroup to finish stores done_seq to done_flag (pinned host memory)
+    unsigned* done_count;      // device, zero between launches
+    unsigned* done_flag;
+    unsigned done_seq;
 };
 
 __device__ __forceinline__ uint32_t ro_mix32(uint32_t x) {
@@ -256,6 +260,18 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
         a.out_xy[2 * g + 1] = a.next_xy[2 * g + 1];
         a.out_err[g] = a.err[g];
         a.out_status[g] = keep ? 1 : 0;
+    }
+    if (a.done_flag) {
+        __threadfence_system();   // this thread's results are visible to the host before the flag can be
+        __syncthreads();
+        if (t == 0) {
+            const unsigned finished = atomicAdd(a.done_count, 1u);
+            if (finished == gridDim.x - 1) {   // every other workgroup has passed its fence
+                *a.done_count = 0;
+                __threadfence_system();
+                *reinterpret_cast<volatile unsigned*>(a.done_flag) = a.done_seq;
+            }
+        }
     }
 }
 
