@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--host-frames", action="store_true", help="headline leg fed from host memory (for profiling that leg alone)")
     ap.add_argument("--no-reject-outliers", action="store_true", help="headline leg without the outlier rejection (for profiling)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-frame / no-rejection / gradient-image legs")
+    ap.add_argument("--streams", type=int, default=0, help="override the workload's stream count (experiments; the JSON line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -233,7 +234,10 @@ def main():
     from feature_tracker_amd import tracker
     from feature_tracker_amd.sharding import reduce_run_totals
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.streams > 0:
+        wl["streams"] = args.streams
+        wl["desc"] = wl["desc"] + f" [stream count overridden: {args.streams}]"
     K, W, R = args.steps, args.warmup, max(1, args.repeats)
     n_frames = W + 1 + R * K                   # the first frame only detects
     threads = min(16, os.cpu_count() or 8)
