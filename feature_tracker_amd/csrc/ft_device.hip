@@ -645,9 +645,33 @@ int ft_set_frames_staged_pyramid(ft_ctx* c, int n, const int* streams, const int
         src[i] = c->stage_dev + (size_t)si * c->stage_bytes_per_slot;
     }
     FT_HIP(c, hipSetDevice(c->device));
-    const int rc = frames_to_pyramid(c, L, n, src, w, h, (size_t)w, max_level, win_w, win_h, achieved);
-    if (rc) return rc;
-    // the staging buffers are free again once the level-0 pass has read them
+    int rc;
+    if (w % 16 == 0 && (size_t)n * w * h >= ((size_t)2 << 20)) {
+        // Many frames: the bus is the limit, so the staged bytes cross it in one linear pass into level 0 and the
+        // pyramid is then built from device memory.  (A frame or two take the fused pass below: one launch less.)
+        const int top = achieved_level(w, h, win_w, win_h, max_level);
+        EventPair ep;
+        prof_begin(c, 0, ep);
+        const int n16 = w * h / 16;
+        for (int first = 0; first < n; first += FRAME_PTRS) {
+            const int m = std::min(FRAME_PTRS, n - first);
+            FramePtrs F{};
+            for (int i = 0; i < m; i++) F.p[i] = src[first + i];
+            hipLaunchKernelGGL(ingest_linear_kernel, dim3((n16 + 255) / 256, m), dim3(256), 0, enq(c), c->arena, L, F, first, w / 16, n16);
+        }
+        FT_HIP(c, hipGetLastError());
+        rc = top > 0 ? run_levels(c, L, w, h, top, true, false, 0, false) : FT_OK;
+        prof_end(c, ep);
+        if (rc) return rc;
+        for (int i = 0; i < n; i++) {
+            c->slots[L.idx[i]] = SlotState{w, h, top + 1, 0};
+            if (achieved) achieved[i] = top;
+        }
+    } else {
+        rc = frames_to_pyramid(c, L, n, src, w, h, (size_t)w, max_level, win_w, win_h, achieved);
+        if (rc) return rc;
+    }
+    // the staging buffers are free again once the pass that reads them has run
     const int e = c->stage_batch_next;
     c->stage_batch_next = (e + 1) % ft_ctx::STAGE_EV_RING;
     FT_HIP(c, hipEventRecord(c->stage_batch_ev[e], enq(c)));

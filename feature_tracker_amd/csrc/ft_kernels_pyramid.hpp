@@ -205,4 +205,15 @@ __global__ void __launch_bounds__(256) ingest_kernel(ArenaDesc A, ImgList L, Fra
     }
 }
 
+// Staged frames (pinned host memory read over the bus: tightly packed rows, w a multiple of 16) -> level 0.  Every wave
+// reads 1 KB of consecutive bytes: in that shape a kernel reads host memory at the rate of a DMA copy (56 GB/s measured),
+// while the 144-byte row pieces of a tile-shaped pass reach 25-35 GB/s.  grid = (chunks of 256 x 16 bytes, image).
+__global__ void __launch_bounds__(256) ingest_linear_kernel(ArenaDesc A, ImgList L, FramePtrs F, int first, int chunks_per_row, int n16) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n16) return;
+    const int row = g / chunks_per_row, c = g - row * chunks_per_row;
+    const uint4 v = reinterpret_cast<const uint4*>(F.p[blockIdx.y])[g];
+    *reinterpret_cast<uint4*>(level_img_w(A, L.idx[first + blockIdx.y], 0) + (size_t)row * A.lv[0].img_pitch + 16 * c) = v;
+}
+
 }  // namespace ftd

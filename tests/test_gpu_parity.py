@@ -100,14 +100,15 @@ def test_ingest_pyramid_single_pass_bit_exact(dev, shape, win, max_level, pad):
                 assert np.array_equal(ctx.download_level(i, 1 - i, l), ref.level(l)), f"image {i} level {l}"
 
 
-def test_staged_host_frames_pyramid_bit_exact(dev):
-    """Host frames through the pinned staging read directly by the level-0 pass; a second round reuses the staging
-    buffers (the staging call waits for the pass that still reads them)."""
-    h, w = 479, 751
-    with _ctx(dev, 752, 480, n_streams=3) as ctx:
+@pytest.mark.parametrize("w,h,n", [(751, 479, 3), (752, 480, 8)])
+def test_staged_host_frames_pyramid_bit_exact(dev, w, h, n):
+    """Host frames through the pinned staging: a few frames (or a width that is no multiple of 16) are read in place by
+    the fused level-0 pass, many frames cross the bus in a linear pass of their own first; later rounds reuse the
+    staging buffers (the staging call waits for the pass that still reads them)."""
+    with _ctx(dev, 752, 480, n_streams=n) as ctx:
         for rnd in range(3):
-            frames = [synth.texture(w, h, seed=200 + 3 * rnd + i) for i in range(3)]
-            ach = ctx.set_frames_host_pyramid([0, 1, 2], [rnd % 2] * 3, frames, max_level=3, win=21)
+            frames = [synth.texture(w, h, seed=200 + n * rnd + i) for i in range(n)]
+            ach = ctx.set_frames_host_pyramid(list(range(n)), [rnd % 2] * n, frames, max_level=3, win=21)
             for i, f in enumerate(frames):
                 ref = O.Pyramid(f, 21, 3)
                 assert ach[i] == ref.levels - 1
