@@ -475,17 +475,76 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         {
             const BilinW bw = bilin_weights(px - ipx, py - ipy);
             const uint32_t wtop = (uint32_t)bw.w00 | ((uint32_t)bw.w01 << 16), wbot = (uint32_t)bw.w10 | ((uint32_t)bw.w11 << 16);
-            // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
-            // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
-            const int boff = ipx + x0 - 1 - RI.rx0;
-            uint32_t Ra[NP], Rb[NP], Rc[NP], Rd[NP];
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
             int sX[SEGLEN], sY[SEGLEN];
 #pragma unroll
             for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
             const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
+            uint32_t Rb[NP], Rc[NP];   // pixel pairs of the two rows the lane's template samples blend (old path: read below)
+            if constexpr (SEGLEN == 8 && !TALL) {
+                // Two steps through LDS.  (1) The integer Scharr gradients of the (wh + 1) x (ww + 1) patch are computed
+                // once, a half row of 12 columns per lane (22 x 2 tasks for 21 x 21), instead of 2.6 times over in the
+                // lanes that blend them; (2) every lane blends its eight samples from two rows of that patch.
+                constexpr int GP = 19;                               // dwords per patch row (pairs of columns), odd
+                __shared__ uint32_t gxl[(WH_MAX + 1) * GP], gyl[(WH_MAX + 1) * GP];
+                const int tpr = (ww + 1 + 11) / 12;                  // tasks per patch row
+                const int n_tasks = (wh + 1) * tpr;
+                for (int task = lane; task < n_tasks; task += 64) {
+                    const int ra = tpr == 2 ? task >> 1 : (tpr == 1 ? task : task / 3), ha = task - ra * tpr;
+                    const int boffA = ipx - 1 - RI.rx0 + 12 * ha;    // byte 0: image column ipx + 12 ha - 1
+                    uint32_t U[7], M[7], L[7];
+                    read_row_pairs_even<7, LK_PITCH>(ilds, ra, boffA, U);
+                    read_row_pairs_even<7, LK_PITCH>(ilds, ra + 1, boffA, M);
+                    read_row_pairs_even<7, LK_PITCH>(ilds, ra + 2, boffA, L);
+                    lk_v2s T0[7], T1[7];
+#pragma unroll
+                    for (int m = 0; m < 7; m++) {
+                        T0[m] = (v2s(U[m]) + v2s(L[m])) * (short)3 + v2s(M[m]) * (short)10;   // <= 4080
+                        T1[m] = v2s(L[m]) - v2s(U[m]);
+                    }
+                    const int gyA = ipy + ra, gxA = ipx + 12 * ha;
+                    const bool row_in = gyA >= 0 && gyA < h;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) {                    // patch columns 12 ha + 2 m, + 1
+                        uint32_t px = u32(T0[m + 1] - T0[m]);
+                        const lk_v2s mid = v2s(next_pair(u32(T1[m + 1]), u32(T1[m])));
+                        uint32_t py = u32((T1[m] + T1[m + 1]) * (short)3 + mid * (short)10);
+                        if (!inside) {                               // the derivative image is zero outside the image
+                            const int gx = gxA + 2 * m;
+                            const uint32_t in = ((row_in && gx >= 0 && gx < w) ? 0xffffu : 0u) | ((row_in && gx + 1 >= 0 && gx + 1 < w) ? 0xffff0000u : 0u);
+                            px &= in; py &= in;
+                        }
+                        gxl[ra * GP + 6 * ha + m] = px;
+                        gyl[ra * GP + 6 * ha + m] = py;
+                    }
+                }
+                lds_fence();
+                // the lane's samples k = 0..7 are patch columns x0 + k, x0 + k + 1 of patch rows rc, rc + 1
+                {
+                    const uint32_t* ga = &gxl[rc * GP + 4 * s];
+                    const uint32_t* gb = &gyl[rc * GP + 4 * s];
+                    uint32_t xa[5], xb[5], ya[5], yb[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) { xa[q] = ga[q]; xb[q] = ga[GP + q]; ya[q] = gb[q]; yb[q] = gb[GP + q]; }
+#pragma unroll
+                    for (int k = 0; k < SEGLEN; k++) {
+                        const int q = k >> 1;
+                        const uint32_t pxa = (k & 1) ? next_pair(xa[q + 1], xa[q]) : xa[q], pxb = (k & 1) ? next_pair(xb[q + 1], xb[q]) : xb[q];
+                        const uint32_t pya = (k & 1) ? next_pair(ya[q + 1], ya[q]) : ya[q], pyb = (k & 1) ? next_pair(yb[q + 1], yb[q]) : yb[q];
+                        sX[k] = dot2_acc(pxb, wbot, dot2_acc(pxa, wtop, sX[k]));
+                        sY[k] = dot2_acc(pyb, wbot, dot2_acc(pya, wtop, sY[k]));
+                    }
+                }
+                // pixel pairs for the template samples: region rows rc + 1, rc + 2, from image column ipx + x0 - 1
+                read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, ipx + x0 - 1 - RI.rx0, Rb);
+                read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, ipx + x0 - 1 - RI.rx0, Rc);
+            } else {
+            // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
+            // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
+            const int boff = ipx + x0 - 1 - RI.rx0;
+            uint32_t Ra[NP], Rd[NP];
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
             const int gy = ipy + rc;
             // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
             // (the column passes through an opaque assembly statement inside the border branch: otherwise the compiler
@@ -497,6 +556,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
             else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, col0, w); }
             __builtin_amdgcn_sched_barrier(0);
+            }
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int m = 0; m < SEGLEN / 2; m++) {
