@@ -120,7 +120,7 @@ struct ft_ctx {
     // every *_async call takes the next sequence number; a fence remembers the number reached when it was recorded
     uint64_t seq = 0;
     static constexpr int FENCE_RING = 16;
-    struct Fence { hipEvent_t ev = nullptr; uint64_t id = 0, seq = 0; uint32_t flag_seq = 0; };
+    struct Fence { hipEvent_t ev = nullptr; uint64_t id = 0, seq = 0; uint32_t flag_seq = 0; bool recorded = false; };
     Fence fences[FENCE_RING];
     uint64_t fence_ids = 0;
 
@@ -1169,8 +1169,9 @@ int ft_fence(ft_ctx* c, uint64_t* token) {
     FT_HIP(c, hipSetDevice(c->device));
     const uint64_t id = ++c->fence_ids;
     ft_ctx::Fence& f = c->fences[id % ft_ctx::FENCE_RING];
-    f.flag_seq = c->tail_flag_seq;   // the queue ends with a launch that reports its own completion
-    FT_HIP(c, hipEventRecord(f.ev, c->q_));
+    f.flag_seq = c->tail_flag_seq;   // the queue ends with a launch that reports its own completion: no event needed
+    f.recorded = f.flag_seq == 0;
+    if (f.recorded) FT_HIP(c, hipEventRecord(f.ev, c->q_));
     f.id = id;
     f.seq = c->seq;
     *token = id;
@@ -1184,7 +1185,7 @@ int ft_wait(ft_ctx* c, uint64_t token) {
     FT_HIP(c, hipSetDevice(c->device));
     bool done = false;
     if (f.flag_seq) {
-        // poll the kernel's own completion flag; give up after a while and take the event (which covers the same work)
+        // poll the kernel's own completion flag; give up after a while and wait for the queue instead
         const volatile unsigned* flag = c->done_flag_host;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; !done; spins++) {
@@ -1193,7 +1194,10 @@ int ft_wait(ft_ctx* c, uint64_t token) {
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    if (!done) FT_HIP(c, hipEventSynchronize(f.ev));
+    if (!done) {
+        if (f.recorded) FT_HIP(c, hipEventSynchronize(f.ev));
+        else FT_HIP(c, hipStreamSynchronize(c->q_));   // (the flag did not come: wait for the whole queue)
+    }
     prof_collect(c);
     return deliver_pending(c, f.seq);
 }
