@@ -193,7 +193,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=100, help="untimed steps before the timed regions (the pipeline needs about 100 steps = 15 ms to reach its steady rate: measured 58-63 M features/s in a first region after 8 or 30 steps, 66 M after 100)")
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the workload's streams dealt to the ranks (s mod N); weak = the full stream count on every rank")
