@@ -185,7 +185,7 @@ def test_lk_forward_backward_and_rect_window(dev):
     nxt = nxt.copy()
     nxt[100:180, 200:320] = np.random.default_rng(2).integers(0, 256, (80, 120), dtype=np.uint8)
     pts = synth.random_points(w, h, 1000, seed=61, border=10)
-    for win in (21, (21, 11)):
+    for win in (21, (21, 11), (24, 21), 17):   # (24, 21): three 12-column tasks per gradient patch row, two passes
         rp, rn = O.Pyramid(prev, win, 4), O.Pyramid(nxt, win, 4)
         flags = dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_FORWARD_BACKWARD
         ref = O.lk_track(rp, rn, pts, win=win, max_level=4, flags=flags, fb_thresh=1.0)
