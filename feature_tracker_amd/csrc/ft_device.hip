@@ -90,6 +90,7 @@ struct ft_ctx {
     std::vector<hipEvent_t> stage_done;
     std::vector<char> stage_busy;
     uint8_t* stage_dev = nullptr;               // device-side address of `stage` (kernels read staged frames over the bus)
+    uint8_t* ingest_dev = nullptr;              // device memory: landing area of a copy command that brings many staged frames at once
     static constexpr int STAGE_EV_RING = 4;
     hipEvent_t stage_batch_ev[STAGE_EV_RING] = {};   // recorded after a kernel that reads staged frames
     int stage_batch_next = 0;
@@ -409,6 +410,8 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
         if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(FT_E_HIP);
         c->stage_dev = (uint8_t*)dp;
     }
+    if (hipMalloc(&p, (size_t)lim->max_width * lim->max_height * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
+    c->ingest_dev = (uint8_t*)p;
     c->stage_done.resize(n_slots_total, nullptr);
     c->stage_busy.assign(n_slots_total, 0);
     c->stage_batch_idx.assign(n_slots_total, -1);
@@ -498,6 +501,7 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_out_host) (void)hipHostFree(c->lk_out_host);
     if (c->lk_out_dev) (void)hipFree(c->lk_out_dev);
     if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
+    if (c->ingest_dev) (void)hipFree(c->ingest_dev);
     if (c->done_count_dev) (void)hipFree(c->done_count_dev);
     if (c->done_flag_host) (void)hipHostFree(c->done_flag_host);
     if (c->match_dev) (void)hipFree(c->match_dev);
@@ -653,6 +657,18 @@ int ft_set_frames_staged_pyramid(ft_ctx* c, int n, const int* streams, const int
         EventPair ep;
         prof_begin(c, 0, ep);
         const int n16 = w * h / 16;
+        // Staging buffers at a constant distance (the same slot of consecutive streams: the usual call) come over with
+        // one copy command, on the copy engine and at its rate whatever else occupies the compute units; then level 0
+        // is written from device memory.  Otherwise the kernel below reads the staging over the bus itself.
+        bool regular = n >= 2 && n <= c->lim.n_streams;
+        const ptrdiff_t dist = n >= 2 ? src[1] - src[0] : 0;
+        for (int i = 2; i < n && regular; i++) regular = src[i] - src[i - 1] == dist;
+        regular = regular && dist >= (ptrdiff_t)w * h;
+        if (regular) {
+            const uint8_t* host0 = c->stage + (src[0] - c->stage_dev);
+            FT_HIP(c, hipMemcpy2DAsync(c->ingest_dev, (size_t)w * h, host0, (size_t)dist, (size_t)w * h, (size_t)n, hipMemcpyHostToDevice, enq(c)));
+            for (int i = 0; i < n; i++) src[i] = c->ingest_dev + (size_t)i * w * h;
+        }
         for (int first = 0; first < n; first += FRAME_PTRS) {
             const int m = std::min(FRAME_PTRS, n - first);
             FramePtrs F{};
