@@ -108,7 +108,11 @@ def test_staged_host_frames_pyramid_bit_exact(dev, w, h, n):
     with _ctx(dev, 752, 480, n_streams=n) as ctx:
         for rnd in range(3):
             frames = [synth.texture(w, h, seed=200 + n * rnd + i) for i in range(n)]
-            ach = ctx.set_frames_host_pyramid(list(range(n)), [rnd % 2] * n, frames, max_level=3, win=21)
+            # round 2 names the streams out of order: their staging buffers are then not at a constant distance, and the
+            # linear pass reads them over the bus itself instead of from the landing area of one copy command
+            order = list(range(n)) if rnd != 2 else [1, 0] + list(range(2, n))
+            ach = ctx.set_frames_host_pyramid(order, [rnd % 2] * n, [frames[i] for i in order], max_level=3, win=21)
+            ach = [ach[order.index(i)] for i in range(n)]
             for i, f in enumerate(frames):
                 ref = O.Pyramid(f, 21, 3)
                 assert ach[i] == ref.levels - 1
