@@ -179,6 +179,18 @@ __device__ __forceinline__ int dot2_to(uint32_t pair, uint32_t wpair, int addend
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(pair), "v"(wpair), "v"(addend));
     return r;
 }
+// the same with a wave-uniform addend taken from a scalar register or an inline constant: no vector register has to
+// be set up with the constant first
+__device__ __forceinline__ int dot2_to_uniform(uint32_t pair, uint32_t wpair, int addend) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(pair), "v"(wpair), "s"(addend));
+    return r;
+}
+__device__ __forceinline__ int dot2_to_zero(uint32_t pair, uint32_t wpair) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "v"(wpair));
+    return r;
+}
 // upper 16-bit field of lo followed by the lower field of hi: the pair one element further along
 __device__ __forceinline__ uint32_t next_pair(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 // low halves of two ints as one 16-bit pair
@@ -199,44 +211,68 @@ __device__ __forceinline__ int reflect101_once(int p, int len) {
 }
 
 struct __attribute__((packed)) LkU32Unaligned { uint32_t v; };
-struct __attribute__((packed, aligned(4))) LkU64Unaligned { uint32_t a, b; };
 
-// load image columns [x_first, x_last] x rows [y_first, y_first + n_rows) into LDS (REFLECT_101 outside the image).
-// Lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...; the LDS array holds 4*MAXR rows.
-// A lane issues all its loads before the first one is consumed, so a region costs one memory round trip.  The
-// caller orders the LDS writes before its reads with lds_fence().
-template <int MAXR, int LK_PITCH>
-__device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
-                                               int x_first, int x_last, int y_first, int n_rows, int lane, int a_reach_w, int a_reach_h) {
+// The interior case of staging in two halves, so that a caller can have the loads of several regions in flight before
+// the first store waits for its data.  A staged row is 48 bytes: lane (q, r) = (lane % 3, lane / 3) moves the 16
+// bytes q of rows r, r + 21, ...
+__device__ __forceinline__ Region region_of(int x_first, int x_last, int y_first, int n_rows) {
     Region R;
     R.rx0 = (x_first >> 2) << 2;
     R.ry0 = y_first;
     R.rwd = (x_last - R.rx0 + 4) >> 2;     // <= LK_RW_DWORDS
-    R.rh = n_rows;                         // <= 4 * MAXR
+    R.rh = n_rows;
+    return R;
+}
+// all staged columns are image columns / all staged rows are image rows
+__device__ __forceinline__ bool region_cols_inside(const Region& R, int w) { return R.rx0 >= 0 && R.rx0 + 4 * LK_RW_DWORDS <= w; }
+__device__ __forceinline__ bool region_rows_inside(const Region& R, int h) { return R.ry0 >= 0 && R.ry0 + R.rh <= h; }
+struct __attribute__((packed, aligned(4))) LkU128Unaligned { uint32_t a, b, c, d; };
+static_assert(LK_RW_DWORDS == 12, "three 16-byte pieces per staged row");
+template <int MAXR> struct LkInteriorRows { LkU128Unaligned v[(4 * MAXR + 20) / 21]; };
+// Columns inside the image.  ROWS_INSIDE: so are the rows; otherwise rows are mirrored (REFLECT_101, one reflection:
+// the caller checks that the level is tall enough for that).
+template <int MAXR, bool ROWS_INSIDE>
+__device__ __forceinline__ void load_interior(LkInteriorRows<MAXR>& rows, const uint8_t* __restrict__ img, uint32_t pitch, int h, const Region& R, int lane) {
+    const int r = (lane * 21846) >> 16, q = lane - 3 * r;      // lane / 3, lane % 3 (exact for lane < 64)
+    const uint32_t xoff = (uint32_t)(R.rx0 + 16 * q);
+#pragma unroll
+    for (int k = 0; k < (4 * MAXR + 20) / 21; k++) {
+        int sy = R.ry0 + r + 21 * k;
+        if (ROWS_INSIDE) {
+            sy = min(sy, h - 1);                               // rows past the region (not stored) stay inside the image
+        } else {
+            sy = max(sy, -sy);
+            sy = max(min(sy, 2 * h - 2 - sy), 0);              // the mirror row; rows past the region: any image row
+        }
+        rows.v[k] = *reinterpret_cast<const LkU128Unaligned*>(img + (__umul24(sy, pitch) + xoff));
+    }
+}
+// The LDS array holds 4*MAXR rows and one more that takes the rows past them, so that no store needs a predicate.
+template <int MAXR, int LK_PITCH>
+__device__ __forceinline__ void store_interior(uint32_t* __restrict__ lds, const LkInteriorRows<MAXR>& rows, int lane) {
+    const int r = (lane * 21846) >> 16, q = lane - 3 * r;
+#pragma unroll
+    for (int k = 0; k < (4 * MAXR + 20) / 21; k++) {
+        uint32_t* d = lds + min(r + 21 * k, 4 * MAXR) * LK_PITCH + 4 * q;
+        d[0] = rows.v[k].a; d[1] = rows.v[k].b; d[2] = rows.v[k].c; d[3] = rows.v[k].d;
+    }
+}
+
+// load image columns [x_first, x_last] x rows [y_first, y_first + n_rows) into LDS (REFLECT_101 outside the image).
+// Border cases: lane (c, rr) = (lane & 15, lane >> 4) owns dword column c of rows rr, rr+4, ...; the LDS array holds
+// 4*MAXR rows and one surplus row.  A lane issues all its loads before the first one is consumed, so a region costs
+// one memory round trip.  The caller orders the LDS writes before its reads with lds_fence().
+template <int MAXR, int LK_PITCH>
+__device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const uint8_t* __restrict__ img, uint32_t pitch, int w, int h,
+                                               int x_first, int x_last, int y_first, int n_rows, int lane, int a_reach_w, int a_reach_h) {
+    Region R = region_of(x_first, x_last, y_first, n_rows);     // rwd <= LK_RW_DWORDS, rh <= 4 * MAXR
     const int c = lane & 15, rr = lane >> 4;
     const int gx = R.rx0 + 4 * c;
     // wave-uniform cases, cheapest first
-    const bool interior = R.rx0 >= 0 && R.rx0 + 4 * LK_RW_DWORDS <= w && R.ry0 >= 0 && R.ry0 + R.rh <= h;
-    if (interior) {
-        // every staged byte is an image byte: no border arithmetic.  Here a lane owns a pair of dwords, lane (c2, r8) =
-        // (lane & 7, lane >> 3) the dwords 2*c2, 2*c2+1 of rows r8, r8+8, ...: half as many loads, LDS stores and
-        // address computations as with one dword per lane.  Rows past the region (never read) are clamped into the
-        // image so that all rows can be loaded without per-row predicates.
-        constexpr int MAXR8 = (4 * MAXR + 7) / 8;
-        const int c2 = lane & 7, r8 = lane >> 3;
-        if (2 * c2 < LK_RW_DWORDS) {
-            uint32_t va[MAXR8], vb[MAXR8];
-#pragma unroll
-            for (int k = 0; k < MAXR8; k++) {
-                const int sy = min(R.ry0 + r8 + 8 * k, h - 1);
-                const LkU64Unaligned q = *reinterpret_cast<const LkU64Unaligned*>(img + (__umul24(sy, pitch) + (uint32_t)(R.rx0 + 8 * c2)));   // uniform base + 32-bit offset
-                va[k] = q.a; vb[k] = q.b;
-            }
-            uint32_t* dst = lds + r8 * LK_PITCH + 2 * c2;
-#pragma unroll
-            for (int k = 0; k < MAXR8; k++)
-                if ((4 * MAXR) % 8 == 0 || r8 + 8 * k < 4 * MAXR) { dst[8 * k * LK_PITCH] = va[k]; dst[8 * k * LK_PITCH + 1] = vb[k]; }
-        }
+    if (region_cols_inside(R, w) && region_rows_inside(R, h)) {     // every staged byte is an image byte: no border arithmetic
+        LkInteriorRows<MAXR> v;
+        load_interior<MAXR, true>(v, img, pitch, h, R, lane);
+        store_interior<MAXR, LK_PITCH>(lds, v, lane);
         return R;
     }
     // The region reaches at most a window plus its margins beyond the image.  On a level larger than that, one
@@ -377,8 +413,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
     constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
     constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
-    __shared__ uint32_t jlds[4 * J_ROWS * LK_PITCH + 4];        // target region (+ slack: row reads are dword-granular)
-    __shared__ uint32_t ilds[4 * I_ROWS * LK_PITCH + 4];        // template region: window + Scharr apron
+    __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region (+ a row for the staging's surplus rows, + slack: row reads are dword-granular)
+    __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: window + Scharr apron
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     const int lane = threadIdx.x;
@@ -423,14 +459,17 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         use_init = true;
     }
 
+    // level-0 size, read once (a load inside the level loop would be a memory round trip at the head of every level)
+    const int w0 = __builtin_amdgcn_readfirstlane(job->w0), h0 = __builtin_amdgcn_readfirstlane(job->h0);
     float outx = gx0, outy = gy0;   // nextPts[i]
     int st = 1;
     float errv = 0.f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float eps_f = (float)a.epsilon, eps_band = eps_f * 1e-4f + 1e-30f;
+    const float inv_area = 1.f / (float)(2 * ww * wh), min_eig_f = (float)a.min_eig;
 
     for (int level = a.max_level; level >= 0; level--) {
-        int w = job->w0, h = job->h0;
+        int w = w0, h = h0;
         for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
         const float scale = __builtin_bit_cast(float, (uint32_t)(127 - level) << 23);   // 2^-level
         float px = tx * scale, py = ty * scale;
@@ -459,11 +498,28 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         const uint8_t* imgJ = level_img(a.A, img_J, level);
         nx -= half_x; ny -= half_y;
         const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-        const Region RI = stage_region<I_ROWS, LK_PITCH>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
-        Region R;
-        R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
-        if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h))
-            R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+        Region RI = region_of(ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3);
+        Region R = region_of(inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN);
+        if (region_cols_inside(RI, w) && region_cols_inside(R, w) && h >= reach_h && !(iny0 < -wh || iny0 >= h)) {
+            // the usual case: one memory round trip for both regions and no byte shuffling; rows outside the image
+            // (regions near the upper or lower border) are read from their mirror rows
+            LkInteriorRows<I_ROWS> vi;
+            LkInteriorRows<J_ROWS> vj;
+            if (region_rows_inside(RI, h) && region_rows_inside(R, h)) {
+                load_interior<I_ROWS, true>(vi, imgI, ipitch, h, RI, lane);
+                load_interior<J_ROWS, true>(vj, imgJ, ipitch, h, R, lane);
+            } else {
+                load_interior<I_ROWS, false>(vi, imgI, ipitch, h, RI, lane);
+                load_interior<J_ROWS, false>(vj, imgJ, ipitch, h, R, lane);
+            }
+            store_interior<I_ROWS, LK_PITCH>(ilds, vi, lane);
+            store_interior<J_ROWS, LK_PITCH>(jlds, vj, lane);
+        } else {
+            RI = stage_region<I_ROWS, LK_PITCH>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
+            R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
+            if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h))
+                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+        }
         lds_fence();
 
         // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
@@ -530,8 +586,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                         const int q = k >> 1;
                         const uint32_t pxa = (k & 1) ? next_pair(xa[q + 1], xa[q]) : xa[q], pxb = (k & 1) ? next_pair(xb[q + 1], xb[q]) : xb[q];
                         const uint32_t pya = (k & 1) ? next_pair(ya[q + 1], ya[q]) : ya[q], pyb = (k & 1) ? next_pair(yb[q + 1], yb[q]) : yb[q];
-                        sX[k] = dot2_acc(pxb, wbot, dot2_acc(pxa, wtop, sX[k]));
-                        sY[k] = dot2_acc(pyb, wbot, dot2_acc(pya, wtop, sY[k]));
+                        sX[k] = dot2_acc(pxb, wbot, dot2_to_uniform(pxa, wtop, 1 << 13));   // 1 << 13: rounding term of the 14-bit descale
+                        sY[k] = dot2_acc(pyb, wbot, dot2_to_uniform(pya, wtop, 1 << 13));
                     }
                 }
                 // pixel pairs for the template samples: region rows rc + 1, rc + 2, from image column ipx + x0 - 1
@@ -562,9 +618,9 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             for (int m = 0; m < SEGLEN / 2; m++) {
                 GX[m] = pack_lo16(sX[2 * m + 1] >> 14, sX[2 * m] >> 14) & keep[m];
                 GY[m] = pack_lo16(sY[2 * m + 1] >> 14, sY[2 * m] >> 14) & keep[m];
-                a11 = dot2_acc(GX[m], GX[m], a11);
-                a12 = dot2_acc(GX[m], GY[m], a12);
-                a22 = dot2_acc(GY[m], GY[m], a22);
+                a11 = m == 0 ? dot2_to_zero(GX[m], GX[m]) : dot2_acc(GX[m], GX[m], a11);
+                a12 = m == 0 ? dot2_to_zero(GX[m], GY[m]) : dot2_acc(GX[m], GY[m], a12);
+                a22 = m == 0 ? dot2_to_zero(GY[m], GY[m]) : dot2_acc(GY[m], GY[m], a22);
             }
 #pragma unroll
             for (int k = 0; k < SEGLEN; k++) {
@@ -578,9 +634,24 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
             A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
         float D = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
-        if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = minEig;
-        if ((double)minEig < a.min_eig || D < 1.1920928955078125e-07f) {
+        // The smaller eigenvalue against the threshold.  Its value is a result only when the caller asks for it (level
+        // 0); otherwise only the outcome of the comparison counts, and the hardware's square root and a reciprocal
+        // multiply (together within 1e-6 of the trace over the area, relative) decide it whenever the value is clear
+        // of the threshold by four times that; the correctly rounded square root and division run only in that band.
+        const float eig_tr = A22 + A11, eig_disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+        bool eig_low;
+        {
+            const float approx = (eig_tr - __builtin_amdgcn_sqrtf(eig_disc)) * inv_area;
+            const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward;
+            if (!want_value && fabsf(approx - min_eig_f) > (eig_tr * inv_area + min_eig_f) * 4e-6f) {
+                eig_low = approx < min_eig_f;
+            } else {
+                const float minEig = (eig_tr - sqrtf(eig_disc)) / (float)(2 * ww * wh);
+                if (want_value) errv = minEig;
+                eig_low = (double)minEig < a.min_eig;
+            }
+        }
+        if (eig_low || D < 1.1920928955078125e-07f) {
             if (level == 0) st = 0;
             if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
             continue;
@@ -613,8 +684,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
                 const int d0 = dot2_acc(p1[2 * m], wbot, dot2_to(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
                 const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_to(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
                 const uint32_t dp = pack_lo16(d1, d0);
-                b1 = dot2_acc(dp, GX[m], b1);
-                b2 = dot2_acc(dp, GY[m], b2);
+                b1 = m == 0 ? dot2_to_zero(dp, GX[m]) : dot2_acc(dp, GX[m], b1);
+                b2 = m == 0 ? dot2_to_zero(dp, GY[m]) : dot2_acc(dp, GY[m], b2);
             }
             float fb1, fb2;
             wave_sum_exact2(b1, b2, fb1, fb2);

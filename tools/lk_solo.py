@@ -1,5 +1,5 @@
-"""LK kernel time against the number of tracked points (needs a GPU): separates the fixed latency of one wavefront's
-four-level chain from the per-point issue cost."""
+"""LK kernel time with one wavefront per compute unit or fewer (needs a GPU): the latency of one wavefront's chain,
+split by parameter set (levels, Newton iterations)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,13 +13,17 @@ for s, q in enumerate(seqs):
     ctx.upload(s, 0, q.frames[0]); ctx.upload(s, 1, q.frames[1])
 ctx.build_pyramid(list(range(S)) * 2, [0] * S + [1] * S, 3, 21, with_gradients=False)
 kp, n, _ = ctx.fast_grid(list(range(S)), [0] * S, 20, 5, 5, 13)
-PER = [int(x) for x in sys.argv[1:]] or [16, 32, 48, 64, 72, 96, 128, 150, 200, 300]
+PER = [int(x) for x in sys.argv[1:]] or [1, 4]
 for per in PER:
     jobs = [dict(prev=(s, 0), next=(s, 1), prev_xy=kp[s, :min(n[s], per), :2].copy()) for s in range(S)]
     npts = sum(len(j["prev_xy"]) for j in jobs)
-    prm = D.LKParams(win=21, max_level=3)
-    ctx.lk_track(jobs, prm); ctx.profile(True); ctx.kernel_times()
-    for _ in range(10): ctx.lk_track(jobs, prm)
-    t = ctx.kernel_times(); ctx.profile(False)
-    us = 1e3 * t['lk_ms'] / t['lk_launches']
-    print(f"{npts:6d} points {us:7.1f} us  {1e3*us/npts:6.2f} ns/point", flush=True)
+    for label, kw in (("full", {}), ("max_iter=1", dict(max_iter=1)), ("max_iter=0", dict(max_iter=0)),
+                      ("max_level=0", dict(max_level=0)), ("max_level=0 max_iter=0", dict(max_level=0, max_iter=0)),
+                      ("max_level=1", dict(max_level=1))):
+        kw = dict(kw)
+        prm = D.LKParams(win=21, max_level=kw.pop("max_level", 3), **kw)
+        ctx.lk_track(jobs, prm); ctx.profile(True); ctx.kernel_times()
+        for _ in range(20): ctx.lk_track(jobs, prm)
+        t = ctx.kernel_times(); ctx.profile(False)
+        us = 1e3 * t['lk_ms'] / t['lk_launches']
+        print(f"{npts:6d} points  {label:24s} {us:7.1f} us", flush=True)
