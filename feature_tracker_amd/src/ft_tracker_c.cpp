@@ -116,6 +116,7 @@ struct ftk_group {
     struct DbJob {
         std::vector<TrackKLT::MonoPlan> payload;
         std::atomic<int> remaining{0};
+        int parts = N_WRITERS;      // threads that share the payload (streams s with s % parts == p go to thread p)
     };
     std::thread writers[N_WRITERS];
     std::mutex wm;
@@ -125,10 +126,25 @@ struct ftk_group {
     std::vector<std::unique_ptr<DbJob>> wbusy;   // jobs in flight (owned here, referenced by the queues)
     long w_posted = 0;
     std::atomic<long> w_done{0};
+    std::atomic<long> w_queued{0};   // jobs handed to the writers so far (what a writer polls before it goes to sleep)
     bool w_stop = false;
 
+    // one thread's share of a job is written; the last one recycles the job
+    void finish_part(DbJob* job) {
+        if (job->remaining.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        {
+            std::lock_guard<std::mutex> lk(wm);
+            for (auto& b : wbusy)
+                if (b.get() == job) { wfree.push_back(std::move(b)); std::swap(b, wbusy.back()); wbusy.pop_back(); break; }
+        }
+        w_done.fetch_add(1, std::memory_order_release);
+    }
     void writer_run(int w) {
+        long seen = 0;   // jobs this writer has taken
         for (;;) {
+            // a short poll bridges back-to-back sets (same rule as the driver: the spin is long only while somebody waits)
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us.load(std::memory_order_relaxed));
+            while (w_queued.load(std::memory_order_acquire) <= seen && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
             DbJob* job;
             {
                 std::unique_lock<std::mutex> lk(wm);
@@ -137,15 +153,9 @@ struct ftk_group {
                 job = wq[w].front();
                 wq[w].pop_front();
             }
-            batch->commit_db(job->payload, w, N_WRITERS);
-            if (job->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // last writer of this set recycles it
-                {
-                    std::lock_guard<std::mutex> lk(wm);
-                    for (auto& b : wbusy)
-                        if (b.get() == job) { wfree.push_back(std::move(b)); std::swap(b, wbusy.back()); wbusy.pop_back(); break; }
-                }
-                w_done.fetch_add(1, std::memory_order_release);
-            }
+            seen++;
+            batch->commit_db(job->payload, w, job->parts);
+            finish_part(job);
         }
     }
     // Handing a set's observations to the writers has a cheap half (take_db: the payload vectors change hands) and a
@@ -160,6 +170,7 @@ struct ftk_group {
             if (!wfree.empty()) { job = std::move(wfree.front()); wfree.pop_front(); }
         }
         if (!job) job.reset(new DbJob());
+        job->parts = N_WRITERS;
         if (!batch->take_db(job->payload)) {
             std::lock_guard<std::mutex> lk(wm);
             wfree.push_back(std::move(job));
@@ -173,15 +184,30 @@ struct ftk_group {
     }
     void queue_db_job() {
         if (!taken) return;
-        taken->remaining.store(N_WRITERS, std::memory_order_release);
+        taken->remaining.store(taken->parts, std::memory_order_release);
         {
             std::lock_guard<std::mutex> lk(wm);
             for (int w = 0; w < N_WRITERS; w++) wq[w].push_back(taken.get());
             wbusy.push_back(std::move(taken));
         }
+        w_queued.fetch_add(1, std::memory_order_release);
         wcv.notify_all();
     }
     void post_db() { take_db_job(); queue_db_job(); }
+    // The last set of a burst, whose database writes nothing is left to hide: the calling thread takes a share of them
+    // next to the writers and returns when all are done.  Earlier jobs are completed first, because a stream's share
+    // changes hands here (s % (N_WRITERS + 1) instead of s % N_WRITERS) and its sets must be applied in order.
+    void write_db_together() {
+        wait_db();
+        take_db_job();
+        if (!taken) return;
+        DbJob* job = taken.get();
+        job->parts = N_WRITERS + 1;
+        queue_db_job();
+        batch->commit_db(job->payload, N_WRITERS, N_WRITERS + 1);
+        finish_part(job);
+        wait_db();
+    }
     void wait_db() {
         long target;
         {
@@ -206,6 +232,9 @@ struct ftk_group {
         if (tm_n && getenv("FT_GROUP_TIMING"))
             fprintf(stderr, "[group %d+%d] %ld sets: mail %.1f begin %.1f stage %.1f complete %.1f after %.1f us\n", first, n, tm_n, tm[0] / tm_n,
                     tm[1] / tm_n, tm[2] / tm_n, tm[3] / tm_n, tm[4] / tm_n);
+        for (const TraceRow& r : trace)
+            fprintf(stderr, "[trace %d] set %ld wait %.0f mail %.0f begun %.0f staged %.0f completed %.0f end %.0f\n", first, r.seq, r.t[0], r.t[1], r.t[2], r.t[3],
+                    r.t[4], r.t[5]);
         if (driver.joinable()) {
             {
                 std::lock_guard<std::mutex> lk(m);
@@ -235,8 +264,12 @@ struct ftk_group {
     // after complete, printed when the group shuts down (a diagnostic for the pipelined feed)
     double tm[5] = {0, 0, 0, 0, 0};
     long tm_n = 0;
+    // FT_GROUP_TRACE=1: the same instants per frame set on the monotonic clock (microseconds), printed at shutdown
+    struct TraceRow { long seq; double t[6]; };
+    std::vector<TraceRow> trace;
     void run() {
         const bool timing = getenv("FT_GROUP_TIMING") != nullptr;
+        const bool tracing = getenv("FT_GROUP_TRACE") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         long unpublished = 0;   // a completed set whose publication was deferred behind the next set's tracking launch
@@ -278,8 +311,12 @@ struct ftk_group {
             const bool more = posted.load(std::memory_order_acquire) > next;
             if (late_detect && !more) {
                 // one set at a time: a hundred or so observations are written faster here than a writer thread wakes up
-                wait_db();            // (sets handed to the writers earlier come first)
-                batch->flush_db();
+                if (n > 4) {
+                    write_db_together();   // thousands of observations: shared with the writer threads
+                } else {
+                    wait_db();             // (sets handed to the writers earlier come first)
+                    batch->flush_db();
+                }
                 publish(next);
             } else if (more && M.rc == FT_OK) {
                 // The next set is waiting: its tracking launch comes first.  This set's observations change hands now
@@ -292,6 +329,10 @@ struct ftk_group {
                 publish(next);
             }
             if (timing) { tm[0] += us(t0, t1); tm[1] += us(t1, t2); tm[2] += us(t2, t3); tm[3] += us(t3, t4); tm[4] += us(t4, now()); tm_n++; }
+            if (tracing && trace.size() < 100000) {
+                auto abs_us = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(t.time_since_epoch()).count(); };
+                trace.push_back(TraceRow{next, {abs_us(t0), abs_us(t1), abs_us(t2), abs_us(t3), abs_us(t4), abs_us(now())}});
+            }
         }
     }
     // hand frame set `seq` (= posted + 1) to the driver; set seq - MAIL_RING + 1 and older must have been collected
@@ -584,6 +625,10 @@ int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void*
 int ftk_batch_flush(ftk_batch* b, long long* tracked, long long* attempted) {
     if (!b) return FT_E_INVALID;
     long long tr = 0, at = 0;
+    // The caller waits for the tail of the pipeline and nothing is left to overlap it with: every waiting side polls
+    // from here on (the sleeps and wake-ups of the throughput setting would add up to a few hundred microseconds over
+    // the last two sets).  The next pipelined feed restores the short spin.
+    for (auto& g : b->groups) g->spin_us.store(1000, std::memory_order_relaxed);
     const int rc = b->collect(b->seq, tr, at);
     for (auto& g : b->groups) g->wait_db();   // every observation is in its database when flush returns
     if (tracked) *tracked = tr;

@@ -5,7 +5,7 @@ import numpy as np, torch
 import bench
 from feature_tracker_amd import tracker
 wl = bench.WORKLOADS["cfg4"]
-K=240
+K=int(os.environ.get('RAMP_STEPS', '240'))
 seqs = bench.make_sequences(wl, K + 2, list(range(wl["streams"])), 16)
 dev = torch.device("cuda", 0)
 dev_frames = [torch.from_numpy(q.frames).to(dev) for q in seqs]
@@ -22,6 +22,7 @@ m=np.array(marks)
 for a in range(0, K-20, 20):
     print(f"steps {a:3d}-{a+20:3d}: {(m[a+20-1]-m[a-1 if a else 0])/ (20 if a else 19)*1e6:7.1f} us/step")
 
+if os.environ.get('RAMP_ONLY'): sys.exit(0)
 # the same from a fresh tracker with synchronous feeds: host stage times of every early step (summed over the groups)
 del f
 f = bench.Feeder(tracker, wl, seqs, dev_frames, 0, 0, 0, False)

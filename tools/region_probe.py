@@ -25,4 +25,4 @@ for r in range(3):
     f.b.flush()
     t_end = time.perf_counter() - t0
     torch.cuda.synchronize()
-    print(f"region {r}: feeds return at (us)", " ".join(f"{1e6 * m:.0f}" for m in marks), f"| flush done {1e6 * t_end:.0f}", flush=True)
+    print(f"region {r}: starts at {1e6 * t0:.0f} on the monotonic clock (FT_GROUP_TRACE=1 prints the groups' instants on it); feeds return at (us)", " ".join(f"{1e6 * m:.0f}" for m in marks), f"| flush done {1e6 * t_end:.0f}", flush=True)
