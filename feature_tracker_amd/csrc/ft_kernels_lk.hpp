@@ -418,7 +418,6 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     const int lane = threadIdx.x;
-    const LKJobDev* job = a.jobs + a.pt_job[pt];
     const int ww = a.win_w, wh = a.win_h;
     const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
     const int x0 = s * SEGLEN;
@@ -436,31 +435,37 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
 
     // forward: template = prev pyramid at prev_xy, target = next pyramid, guess from guess_xy / H / prev
     // backward: template = next pyramid at the forward result, target = prev pyramid, guess = original point
+    // Everything indexed by the point is loaded in one batch, then every field of the job record the kernel uses in a
+    // second one: a wave starts with two memory round trips behind the kernel arguments instead of one per field.
+    const float* t_src = a.backward ? a.next_xy : a.prev_xy;
+    const float* g_src = a.backward ? a.prev_xy : a.guess_xy;
+    const int job_i = a.pt_job[pt];
+    const float tx = t_src[2 * pt], ty = t_src[2 * pt + 1];
+    float gx0 = g_src[2 * pt], gy0 = g_src[2 * pt + 1];
+    const LKJobDev* job = a.jobs + job_i;
     const int img_I = a.backward ? job->img_next : job->img_prev;
     const int img_J = a.backward ? job->img_prev : job->img_next;
-    float tx, ty, gx0, gy0;
-    bool use_init;
+    const int job_use_H = job->use_H, job_use_stereo = job->use_stereo;
+    float H[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) H[k] = job->H[k];
+    const int w0 = job->w0, h0 = job->h0;      // level-0 size (a load inside the level loop would be a round trip per level)
+    // (the empty statement uses all of them here, so that the loads are issued together rather than where a branch
+    // first needs each)
+    asm volatile("" ::"s"(img_I), "s"(img_J), "s"(job_use_H), "s"(job_use_stereo), "s"(w0), "s"(h0), "s"(H[0]), "s"(H[1]), "s"(H[2]), "s"(H[3]),
+                 "s"(H[4]), "s"(H[5]), "s"(H[6]), "s"(H[7]), "s"(H[8]));
+    bool use_init = true;
     if (!a.backward) {
-        tx = a.prev_xy[2 * pt]; ty = a.prev_xy[2 * pt + 1];
-        if (job->use_H) {
-            const float* H = job->H;
+        if (job_use_H) {
             const float p0 = H[0] * tx + H[1] * ty + H[2];
             const float p1 = H[3] * tx + H[4] * ty + H[5];
             const float p2 = H[6] * tx + H[7] * ty + H[8];
             gx0 = p0 / p2; gy0 = p1 / p2;
-            use_init = true;
         } else {
-            gx0 = a.guess_xy[2 * pt]; gy0 = a.guess_xy[2 * pt + 1];
-            use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0 || job->use_stereo != 0;   // stereo guesses were written on the device
+            use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0 || job_use_stereo != 0;   // stereo guesses were written on the device
         }
-    } else {
-        tx = a.next_xy[2 * pt]; ty = a.next_xy[2 * pt + 1];
-        gx0 = a.prev_xy[2 * pt]; gy0 = a.prev_xy[2 * pt + 1];
-        use_init = true;
     }
 
-    // level-0 size, read once (a load inside the level loop would be a memory round trip at the head of every level)
-    const int w0 = __builtin_amdgcn_readfirstlane(job->w0), h0 = __builtin_amdgcn_readfirstlane(job->h0);
     float outx = gx0, outy = gy0;   // nextPts[i]
     int st = 1;
     float errv = 0.f;
