@@ -81,10 +81,11 @@ int main() {
     const Run plain = run(1, false);
     const Run piped = run(2, true);
     const Run piped4 = run(4, true);
+    const Run piped1 = run(1, true);   // eight streams in one group: the last set's database writes are shared with the writers
     long long plain_total = 0;
     for (size_t i = 0; i + 1 < plain.tracked.size(); i++) plain_total += plain.tracked[i];
     CHECK(plain_total > 200);
-    for (const Run* r : {&piped, &piped4}) {
+    for (const Run* r : {&piped, &piped4, &piped1}) {
         CHECK(r->tracked.back() == plain_total);
         for (int s = 0; s < S; s++) {
             CHECK(r->ids[(size_t)s] == plain.ids[(size_t)s]);
