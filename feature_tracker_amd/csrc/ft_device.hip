@@ -130,6 +130,7 @@ struct ft_ctx {
 
     // timing
     int profile = 0;   // bit 0: time kernel groups with events, bit 1: count LK work (iteration counters)
+    int lk_pair_max = 2048;   // points per tracking launch up to which lk_pair_kernel runs (FT_LK_PAIR_MAX overrides it: 0 = never)
     std::vector<EventPair> ev_inflight;
     std::vector<EventPair> ev_pool;
     ft_kernel_time times{};
@@ -337,6 +338,13 @@ static int stage_rows(ft_ctx* c, int si, const uint8_t* host, int w, int h, size
 
 template <int SEGLEN>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
+    // Up to one wavefront pair per wave slot pair of the device the two-wave form is the faster one (its chain of
+    // dependent steps is a third shorter); beyond that the idle halves of the pairs cost more than the chain saves.
+    if (total <= c->lk_pair_max) {
+        if (a.win_h > 21) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        else hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        return;
+    }
     if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
     else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
 }
@@ -379,6 +387,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     if (!c) return FT_E_NOMEM;
     c->device = device;
     c->lim = *lim;
+    if (const char* e = getenv("FT_LK_PAIR_MAX")) c->lk_pair_max = atoi(e);
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);
     if (hipStreamCreateWithFlags(&c->q_, hipStreamNonBlocking) != hipSuccess) return fail(FT_E_HIP);

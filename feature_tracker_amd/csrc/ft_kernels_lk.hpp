@@ -269,9 +269,12 @@ __device__ __forceinline__ Region stage_region(uint32_t* __restrict__ lds, const
     const int c = lane & 15, rr = lane >> 4;
     const int gx = R.rx0 + 4 * c;
     // wave-uniform cases, cheapest first
-    if (region_cols_inside(R, w) && region_rows_inside(R, h)) {     // every staged byte is an image byte: no border arithmetic
+    if (region_cols_inside(R, w) && (region_rows_inside(R, h) || h >= a_reach_h)) {
+        // every staged column is an image column: no byte shuffling; rows outside the image (one reflection is exact
+        // on a level of that height) are read from their mirror rows
         LkInteriorRows<MAXR> v;
-        load_interior<MAXR, true>(v, img, pitch, h, R, lane);
+        if (region_rows_inside(R, h)) load_interior<MAXR, true>(v, img, pitch, h, R, lane);
+        else load_interior<MAXR, false>(v, img, pitch, h, R, lane);
         store_interior<MAXR, LK_PITCH>(lds, v, lane);
         return R;
     }
@@ -747,6 +750,392 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     }
 
     if (lane == 0) {
+        if (!a.backward) {
+            a.next_xy[2 * pt] = outx;
+            a.next_xy[2 * pt + 1] = outy;
+            a.status[pt] = (uint8_t)st;
+            a.err[pt] = errv;
+        } else {
+            // forward-backward consistency: the backward track must succeed and return to the original point
+            const float dx = outx - gx0, dy = outy - gy0;
+            const float d2 = dx * dx + dy * dy;
+            if (!st || !(d2 <= a.fb_thresh2)) a.status[pt] = 0;
+        }
+    }
+}
+
+// The same tracking with two wavefronts per feature.  The template of a level (staging of the I region, Scharr patch,
+// blends, the 2x2 matrix and its tests) does not depend on the tracking result, only the Newton iterations on J do.
+// Wave 1 (the templater) therefore works one level ahead of wave 0 (the tracker): while the tracker iterates on level
+// l, the templater prepares level l - 1 and hands it over through LDS (the per-lane template registers Cw, GX, GY, the
+// matrix, the outcome of its tests).  Both waves pass the same two workgroup barriers in every level, whatever the
+// level's outcome: the first says "the template is in LDS", the second "the tracker has taken it"; in between only
+// the tracker touches the hand-over area, outside only the templater.  The chain of dependent steps of a feature gets
+// a third shorter; the arithmetic, and so every result, is that of lk_kernel.
+template <int SEGLEN, bool TALL>
+__global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
+    constexpr int WH_MAX = TALL ? 32 : 21;
+    constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
+    constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
+    constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
+    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
+    __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region: the tracker's
+    __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: the templater's
+    __shared__ uint32_t hand[2 * SEGLEN * 64];                  // hand-over: Cw[SEGLEN], GX[SEGLEN/2], GY[SEGLEN/2] of every lane
+    __shared__ float hand_f[4];                                 // A11, A12, A22, smaller eigenvalue (when asked for)
+    __shared__ int hand_code;                                   // 0: template ready, 1: window outside the image, 2: matrix tests failed
+    const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
+    if (pt >= a.total) return;
+    const int lane = threadIdx.x & 63;
+    const bool templater = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) != 0;
+    const int ww = a.win_w, wh = a.win_h;
+    const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
+    const int x0 = s * SEGLEN;
+    const bool row_ok = r < wh;
+    const int rc = row_ok ? r : wh - 1;          // lanes below the window reuse its last row (results masked)
+    const int ext_w = a.segs * SEGLEN;           // columns the lanes touch: [0, ext_w]
+    const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
+    // smallest level size for which a staged region needs at most one reflection per axis (with some slack)
+    const int reach_w = ext_w + 2 * LK_MARGIN + 8, reach_h = wh + 2 * LK_MARGIN + 8;
+    // which of the lane's samples belong to the window: 16-bit masks for the packed (sample 2m, sample 2m+1) pairs
+    const int n_valid = row_ok ? min(max(ww - x0, 0), SEGLEN) : 0;
+    uint32_t keep[SEGLEN / 2];
+#pragma unroll
+    for (int m = 0; m < SEGLEN / 2; m++) keep[m] = (n_valid > 2 * m ? 0xffffu : 0u) | (n_valid > 2 * m + 1 ? 0xffff0000u : 0u);
+
+    // forward: template = prev pyramid at prev_xy, target = next pyramid, guess from guess_xy / H / prev
+    // backward: template = next pyramid at the forward result, target = prev pyramid, guess = original point
+    // Everything indexed by the point is loaded in one batch, then every field of the job record the kernel uses in a
+    // second one: a wave starts with two memory round trips behind the kernel arguments instead of one per field.
+    const float* t_src = a.backward ? a.next_xy : a.prev_xy;
+    const float* g_src = a.backward ? a.prev_xy : a.guess_xy;
+    const int job_i = a.pt_job[pt];
+    const float tx = t_src[2 * pt], ty = t_src[2 * pt + 1];
+    float gx0 = g_src[2 * pt], gy0 = g_src[2 * pt + 1];
+    const LKJobDev* job = a.jobs + job_i;
+    const int img_I = a.backward ? job->img_next : job->img_prev;
+    const int img_J = a.backward ? job->img_prev : job->img_next;
+    const int job_use_H = job->use_H, job_use_stereo = job->use_stereo;
+    float H[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) H[k] = job->H[k];
+    const int w0 = job->w0, h0 = job->h0;      // level-0 size (a load inside the level loop would be a round trip per level)
+    // (the empty statement uses all of them here, so that the loads are issued together rather than where a branch
+    // first needs each)
+    asm volatile("" ::"s"(img_I), "s"(img_J), "s"(job_use_H), "s"(job_use_stereo), "s"(w0), "s"(h0), "s"(H[0]), "s"(H[1]), "s"(H[2]), "s"(H[3]),
+                 "s"(H[4]), "s"(H[5]), "s"(H[6]), "s"(H[7]), "s"(H[8]));
+    bool use_init = true;
+    if (!a.backward) {
+        if (job_use_H) {
+            const float p0 = H[0] * tx + H[1] * ty + H[2];
+            const float p1 = H[3] * tx + H[4] * ty + H[5];
+            const float p2 = H[6] * tx + H[7] * ty + H[8];
+            gx0 = p0 / p2; gy0 = p1 / p2;
+        } else {
+            use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0 || job_use_stereo != 0;   // stereo guesses were written on the device
+        }
+    }
+
+    float outx = gx0, outy = gy0;   // nextPts[i]
+    int st = 1;
+    float errv = 0.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps_f = (float)a.epsilon, eps_band = eps_f * 1e-4f + 1e-30f;
+    const float inv_area = 1.f / (float)(2 * ww * wh), min_eig_f = (float)a.min_eig;
+
+    for (int level = a.max_level; level >= 0; level--) {
+        int w = w0, h = h0;
+        for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
+        const float scale = __builtin_bit_cast(float, (uint32_t)(127 - level) << 23);   // 2^-level
+        float px = tx * scale, py = ty * scale;
+        float nx, ny;
+        if (level == a.max_level) {
+            if (use_init) { nx = outx * scale; ny = outy * scale; }
+            else { nx = px; ny = py; }
+        } else {
+            nx = outx * 2.f; ny = outy * 2.f;
+        }
+        outx = nx; outy = ny;
+        int n_iter = -1;
+
+        px -= half_x; py -= half_y;
+        // positions are identical in all lanes: keep the integer parts in scalar registers
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
+        const bool tmpl_out = ipx < -ww || ipx >= w || ipy < -wh || ipy >= h;
+        const uint32_t ipitch = a.A.lv[level].img_pitch;
+        const uint8_t* imgI = level_img(a.A, img_I, level);
+        const uint8_t* imgJ = level_img(a.A, img_J, level);
+        nx -= half_x; ny -= half_y;
+        Region R;
+        R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
+        int Cw[SEGLEN];
+        uint32_t GX[SEGLEN / 2], GY[SEGLEN / 2];
+        float A11 = 0.f, A12 = 0.f, A22 = 0.f;
+
+        // ---- before the hand-over: the templater builds this level's template, the tracker stages its J region ----
+        if (templater) {
+            int code = 1;
+            float eig_value = 0.f;
+            if (!tmpl_out) {
+                const Region RI = stage_region<I_ROWS, LK_PITCH>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
+                lds_fence();
+                // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
+                // Kept for the iterations: Cw[k] = 256 - 512 * I(k) (folds the subtraction of the template sample into the
+                // accumulator of the target blend), and the gradients as pairs GX[m] = (Ix(2m), Ix(2m+1)), GY[m] likewise.
+                {
+                    const BilinW bw = bilin_weights(px - ipx, py - ipy);
+                    const uint32_t wtop = (uint32_t)bw.w00 | ((uint32_t)bw.w01 << 16), wbot = (uint32_t)bw.w10 | ((uint32_t)bw.w11 << 16);
+                    int sX[SEGLEN], sY[SEGLEN];
+        #pragma unroll
+                    for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
+                    const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
+                    uint32_t Rb[NP], Rc[NP];   // pixel pairs of the two rows the lane's template samples blend (old path: read below)
+                    if constexpr (SEGLEN == 8 && !TALL) {
+                        // Two steps through LDS.  (1) The integer Scharr gradients of the (wh + 1) x (ww + 1) patch are computed
+                        // once, a half row of 12 columns per lane (22 x 2 tasks for 21 x 21), instead of 2.6 times over in the
+                        // lanes that blend them; (2) every lane blends its eight samples from two rows of that patch.
+                        constexpr int GP = 19;                               // dwords per patch row (pairs of columns), odd
+                        __shared__ uint32_t gxl[(WH_MAX + 1) * GP], gyl[(WH_MAX + 1) * GP];
+                        const int tpr = (ww + 1 + 11) / 12;                  // tasks per patch row
+                        const int n_tasks = (wh + 1) * tpr;
+                        for (int task = lane; task < n_tasks; task += 64) {
+                            const int ra = tpr == 2 ? task >> 1 : (tpr == 1 ? task : task / 3), ha = task - ra * tpr;
+                            const int boffA = ipx - 1 - RI.rx0 + 12 * ha;    // byte 0: image column ipx + 12 ha - 1
+                            uint32_t U[7], M[7], L[7];
+                            read_row_pairs_even<7, LK_PITCH>(ilds, ra, boffA, U);
+                            read_row_pairs_even<7, LK_PITCH>(ilds, ra + 1, boffA, M);
+                            read_row_pairs_even<7, LK_PITCH>(ilds, ra + 2, boffA, L);
+                            lk_v2s T0[7], T1[7];
+        #pragma unroll
+                            for (int m = 0; m < 7; m++) {
+                                T0[m] = (v2s(U[m]) + v2s(L[m])) * (short)3 + v2s(M[m]) * (short)10;   // <= 4080
+                                T1[m] = v2s(L[m]) - v2s(U[m]);
+                            }
+                            const int gyA = ipy + ra, gxA = ipx + 12 * ha;
+                            const bool row_in = gyA >= 0 && gyA < h;
+        #pragma unroll
+                            for (int m = 0; m < 6; m++) {                    // patch columns 12 ha + 2 m, + 1
+                                uint32_t px = u32(T0[m + 1] - T0[m]);
+                                const lk_v2s mid = v2s(next_pair(u32(T1[m + 1]), u32(T1[m])));
+                                uint32_t py = u32((T1[m] + T1[m + 1]) * (short)3 + mid * (short)10);
+                                if (!inside) {                               // the derivative image is zero outside the image
+                                    const int gx = gxA + 2 * m;
+                                    const uint32_t in = ((row_in && gx >= 0 && gx < w) ? 0xffffu : 0u) | ((row_in && gx + 1 >= 0 && gx + 1 < w) ? 0xffff0000u : 0u);
+                                    px &= in; py &= in;
+                                }
+                                gxl[ra * GP + 6 * ha + m] = px;
+                                gyl[ra * GP + 6 * ha + m] = py;
+                            }
+                        }
+                        lds_fence();
+                        // the lane's samples k = 0..7 are patch columns x0 + k, x0 + k + 1 of patch rows rc, rc + 1
+                        {
+                            const uint32_t* ga = &gxl[rc * GP + 4 * s];
+                            const uint32_t* gb = &gyl[rc * GP + 4 * s];
+                            uint32_t xa[5], xb[5], ya[5], yb[5];
+        #pragma unroll
+                            for (int q = 0; q < 5; q++) { xa[q] = ga[q]; xb[q] = ga[GP + q]; ya[q] = gb[q]; yb[q] = gb[GP + q]; }
+        #pragma unroll
+                            for (int k = 0; k < SEGLEN; k++) {
+                                const int q = k >> 1;
+                                const uint32_t pxa = (k & 1) ? next_pair(xa[q + 1], xa[q]) : xa[q], pxb = (k & 1) ? next_pair(xb[q + 1], xb[q]) : xb[q];
+                                const uint32_t pya = (k & 1) ? next_pair(ya[q + 1], ya[q]) : ya[q], pyb = (k & 1) ? next_pair(yb[q + 1], yb[q]) : yb[q];
+                                sX[k] = dot2_acc(pxb, wbot, dot2_to_uniform(pxa, wtop, 1 << 13));   // 1 << 13: rounding term of the 14-bit descale
+                                sY[k] = dot2_acc(pyb, wbot, dot2_to_uniform(pya, wtop, 1 << 13));
+                            }
+                        }
+                        // pixel pairs for the template samples: region rows rc + 1, rc + 2, from image column ipx + x0 - 1
+                        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, ipx + x0 - 1 - RI.rx0, Rb);
+                        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, ipx + x0 - 1 - RI.rx0, Rc);
+                    } else {
+                    // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
+                    // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
+                    const int boff = ipx + x0 - 1 - RI.rx0;
+                    uint32_t Ra[NP], Rd[NP];
+                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
+                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
+                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
+                    const int gy = ipy + rc;
+                    // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
+                    // (the column passes through an opaque assembly statement inside the border branch: otherwise the compiler
+                    // hoists the border masks' comparisons above the branch and every window pays for them)
+                    if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
+                    else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, col0, w); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 3, boff, Rd);
+                    if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
+                    else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, col0, w); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    }
+                    int a11 = 0, a12 = 0, a22 = 0;
+        #pragma unroll
+                    for (int m = 0; m < SEGLEN / 2; m++) {
+                        GX[m] = pack_lo16(sX[2 * m + 1] >> 14, sX[2 * m] >> 14) & keep[m];
+                        GY[m] = pack_lo16(sY[2 * m + 1] >> 14, sY[2 * m] >> 14) & keep[m];
+                        a11 = m == 0 ? dot2_to_zero(GX[m], GX[m]) : dot2_acc(GX[m], GX[m], a11);
+                        a12 = m == 0 ? dot2_to_zero(GX[m], GY[m]) : dot2_acc(GX[m], GY[m], a12);
+                        a22 = m == 0 ? dot2_to_zero(GY[m], GY[m]) : dot2_acc(GY[m], GY[m], a22);
+                    }
+        #pragma unroll
+                    for (int k = 0; k < SEGLEN; k++) {
+                        // sample k blends pixel columns c = k+1, k+2 of region rows rc+1, rc+2
+                        const uint32_t pb = (k & 1) ? Rb[(k + 1) / 2] : next_pair(Rb[k / 2 + 1], Rb[k / 2]);
+                        const uint32_t pc = (k & 1) ? Rc[(k + 1) / 2] : next_pair(Rc[k / 2 + 1], Rc[k / 2]);
+                        const int iw = dot2_acc(pc, wbot, dot2_to(pb, wtop, 256)) >> 9;
+                        Cw[k] = 256 - (iw << 9);
+                    }
+                    wave_sum_exact3(a11, a22, a12, A11, A22, A12);
+                    A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+                }
+                const float D = A11 * A22 - A12 * A12;
+                // the smaller eigenvalue against the threshold: see lk_kernel
+                const float eig_tr = A22 + A11, eig_disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+                bool eig_low;
+                {
+                    const float approx = (eig_tr - __builtin_amdgcn_sqrtf(eig_disc)) * inv_area;
+                    const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward;
+                    if (!want_value && fabsf(approx - min_eig_f) > (eig_tr * inv_area + min_eig_f) * 4e-6f) {
+                        eig_low = approx < min_eig_f;
+                    } else {
+                        const float minEig = (eig_tr - sqrtf(eig_disc)) / (float)(2 * ww * wh);
+                        eig_value = minEig;
+                        eig_low = (double)minEig < a.min_eig;
+                    }
+                }
+                code = (eig_low || D < 1.1920928955078125e-07f) ? 2 : 0;
+#pragma unroll
+                for (int k = 0; k < SEGLEN; k++) hand[k * 64 + lane] = (uint32_t)Cw[k];
+#pragma unroll
+                for (int m = 0; m < SEGLEN / 2; m++) {
+                    hand[(SEGLEN + m) * 64 + lane] = GX[m];
+                    hand[(SEGLEN + SEGLEN / 2 + m) * 64 + lane] = GY[m];
+                }
+            }
+            if (lane == 0) { hand_f[0] = A11; hand_f[1] = A12; hand_f[2] = A22; hand_f[3] = eig_value; hand_code = code; }
+        } else if (!tmpl_out) {
+            const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
+            if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h)) {
+                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+                lds_fence();
+            }
+        }
+        __syncthreads();   // the template of this level is in LDS
+        int code = 1;
+        float eig_value = 0.f;
+        if (!templater) {
+            code = hand_code;
+            if (code == 0) {
+#pragma unroll
+                for (int k = 0; k < SEGLEN; k++) Cw[k] = (int)hand[k * 64 + lane];
+#pragma unroll
+                for (int m = 0; m < SEGLEN / 2; m++) {
+                    GX[m] = hand[(SEGLEN + m) * 64 + lane];
+                    GY[m] = hand[(SEGLEN + SEGLEN / 2 + m) * 64 + lane];
+                }
+            }
+            A11 = hand_f[0]; A12 = hand_f[1]; A22 = hand_f[2]; eig_value = hand_f[3];
+        }
+        __syncthreads();   // ... and the tracker has taken it: the templater goes on to the next level
+        if (templater) continue;
+
+        if (code == 1) {            // the template window lies outside the image
+            if (level == 0) { st = 0; errv = 0.f; }
+            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+        } else {
+            if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = eig_value;
+            if (code == 2) {        // flat or degenerate template
+                if (level == 0) st = 0;
+                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+            } else {
+                float D = A11 * A22 - A12 * A12;
+                D = 1.f / D;
+
+                // ---- Newton iterations on the target image, fed from LDS ----
+                float pdx = 0.f, pdy = 0.f;
+                n_iter = 0;
+                for (int j = 0; j < a.max_iter; j++) {
+                    const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
+                    if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
+                        if (level == 0) st = 0;
+                        break;
+                    }
+                    n_iter = j + 1;
+                    if (!region_holds(R, inx, iny, ext_w, wh)) {
+                        R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+                        lds_fence();
+                    }
+                    const BilinW jw = bilin_weights(nx - inx, ny - iny);
+                    const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
+                    uint32_t p0[SEGLEN], p1[SEGLEN];
+                    const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
+                    read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
+                    read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
+                    int b1 = 0, b2 = 0;
+        #pragma unroll
+                    for (int m = 0; m < SEGLEN / 2; m++) {
+                        const int d0 = dot2_acc(p1[2 * m], wbot, dot2_to(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
+                        const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_to(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
+                        const uint32_t dp = pack_lo16(d1, d0);
+                        b1 = m == 0 ? dot2_to_zero(dp, GX[m]) : dot2_acc(dp, GX[m], b1);
+                        b2 = m == 0 ? dot2_to_zero(dp, GY[m]) : dot2_acc(dp, GY[m], b2);
+                    }
+                    float fb1, fb2;
+                    wave_sum_exact2(b1, b2, fb1, fb2);
+                    fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
+                    const float dx = (A12 * fb2 - A22 * fb1) * D;
+                    const float dy = (A12 * fb1 - A11 * fb2) * D;
+                    nx += dx; ny += dy;
+                    outx = nx + half_x; outy = ny + half_y;
+                    // delta . delta <= epsilon in double precision, as the reference computes it.  The float value decides
+                    // whenever it is clear of the bound by far more than its rounding error (a few 1e-7 relative); the double
+                    // arithmetic, at half the issue rate, runs only in the band around the bound.  Uniform for the wave.
+                    {
+                        const float s = dx * dx + dy * dy;
+                        const bool far = fabsf(s - eps_f) > eps_band;
+                        if (far ? s < eps_f : (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
+                    }
+                    // |dx + pdx| < 0.01 and |dy + pdy| < 0.01 in double precision: for a float, "< 0.01" is "< the float above 0.01"
+                    if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
+                        outx -= dx * 0.5f; outy -= dy * 0.5f;
+                        break;
+                    }
+                    pdx = dx; pdy = dy;
+                }
+                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+
+                // ---- residual at the final position (level 0 only) ----
+                if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
+                    const float qx = outx - half_x, qy = outy - half_y;
+                    const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
+                    if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
+                        st = 0;
+                    } else if (!(a.flags & FT_LK_NO_ERROR)) {
+                        if (!region_holds(R, iqx, iqy, ext_w, wh)) {
+                            R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+                            lds_fence();
+                        }
+                        const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
+                        const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
+                        uint32_t p0[SEGLEN], p1[SEGLEN];
+                        const int boff = iqx - R.rx0 + x0, row = iqy - R.ry0 + rc;
+                        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
+                        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
+                        int e = 0;
+        #pragma unroll
+                        for (int k = 0; k < SEGLEN; k++) {
+                            const int diff = dot2_acc(p1[k], wbot, dot2_to(p0[k], wtop, Cw[k])) >> 9;
+                            if (k < n_valid) e += abs(diff);
+                        }
+                        const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
+                        errv = errsum * 1.f / (float)(32 * ww * wh);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
+            }
+        }
+    }
+
+    if (!templater && lane == 0) {
         if (!a.backward) {
             a.next_xy[2 * pt] = outx;
             a.next_xy[2 * pt + 1] = outy;

@@ -21,6 +21,14 @@ def dev():
     return D
 
 
+@pytest.fixture(params=["one_wave_per_point", "two_waves_per_point"])
+def lk_form(request, monkeypatch):
+    """The tracking kernel has two forms (one wavefront per point; a tracker / templater pair per point, used for
+    launches of up to 2048 points): contexts created inside the test run every launch with the named one."""
+    monkeypatch.setenv("FT_LK_PAIR_MAX", "0" if request.param == "one_wave_per_point" else "1000000000")
+    return request.param
+
+
 def _ctx(D, w, h, **kw):
     args = dict(max_levels=6, n_streams=2, n_slots=2, max_points=20000, max_grid_cells=400, max_per_cell=32)
     args.update(kw)
@@ -135,7 +143,7 @@ def _compare_lk(gpu, ref, min_agree=STATUS_AGREE):
 
 @pytest.mark.parametrize("win,max_level,shape,n", [(21, 3, (480, 752), 150), (15, 3, (480, 752), 150), (21, 4, (720, 1280), 2000),
                                                     (9, 2, (240, 320), 300), (31, 2, (480, 752), 200)])
-def test_lk_matches_oracle(dev, win, max_level, shape, n):
+def test_lk_matches_oracle(dev, win, max_level, shape, n, lk_form):
     h, w = shape
     prev, nxt = synth.shifted_pair(w, h, dx=4, dy=-3, seed=40 + win)
     nxt = np.clip(nxt.astype(np.int16) + np.random.default_rng(1).integers(-3, 4, nxt.shape), 0, 255).astype(np.uint8)
@@ -152,7 +160,7 @@ def test_lk_matches_oracle(dev, win, max_level, shape, n):
     assert np.array_equal(out[0], ref[0])          # exact sums on both sides: positions are bit-identical
 
 
-def test_lk_initial_guess_no_initial_flow_and_min_eig(dev):
+def test_lk_initial_guess_no_initial_flow_and_min_eig(dev, lk_form):
     w, h = 376, 240
     prev, nxt = synth.shifted_pair(w, h, dx=6, dy=5, seed=50)
     pts = synth.random_points(w, h, 400, seed=51, border=5)
@@ -183,7 +191,7 @@ def test_lk_initial_guess_no_initial_flow_and_min_eig(dev):
         assert (ref[1] == 0).any()
 
 
-def test_lk_forward_backward_and_rect_window(dev):
+def test_lk_forward_backward_and_rect_window(dev, lk_form):
     w, h = 640, 360
     prev, nxt = synth.shifted_pair(w, h, dx=3, dy=2, seed=60)
     nxt = nxt.copy()
@@ -202,7 +210,7 @@ def test_lk_forward_backward_and_rect_window(dev):
         assert 0 < (ref[1] == 0).sum() < len(pts)
 
 
-def test_lk_batched_jobs_and_gyro_seed(dev):
+def test_lk_batched_jobs_and_gyro_seed(dev, lk_form):
     w, h = 376, 240
     K4 = np.array([300.0, 300.0, 188.0, 120.0], dtype=np.float32)
     R, _ = O.integrate_gyro(np.arange(0, 1, 0.005) + 0.001, np.tile([0.01, -0.02, 0.3], (200, 1)), 0.5, 0.55, np.eye(3))
@@ -262,7 +270,7 @@ def test_fast_grid_batched_and_plateaus(dev):
         assert np.array_equal(out[i, : n_out[i]], ref)
 
 
-def test_full_size_4k_frame_10k_features(dev):
+def test_full_size_4k_frame_10k_features(dev, lk_form):
     """The largest configuration (3840x2160, up to 10 000 features, maxLevel 5, grid 26x15) against the CPU checker."""
     w, h = 3840, 2160
     prev, nxt = synth.shifted_pair(w, h, dx=5, dy=-3, seed=500)
@@ -324,7 +332,7 @@ def test_properties_at_the_benchmark_batch_size(dev):
     assert n_inner > S * 60
 
 
-def test_ragged_empty_and_full_batches(dev):
+def test_ragged_empty_and_full_batches(dev, lk_form):
     """The shapes a caller can throw at the batched entry points: a full batch of 256 small images, jobs with no
     points, one point, and only lost points next to ordinary ones, a flat image without any corner."""
     n_img, w, h = 256, 96, 64
@@ -399,7 +407,7 @@ def test_reject_outliers_degenerate_sets(dev):
             ctx.reject_outliers([dict(prev_xy=np.zeros((601, 2)), next_xy=np.zeros((601, 2)), calib_prev=calib)])
 
 
-def test_lk_with_outlier_rejection_equals_lk_then_oracle_rejection(dev):
+def test_lk_with_outlier_rejection_equals_lk_then_oracle_rejection(dev, lk_form):
     """FT_LK_REJECT_OUTLIERS = the plain LK result with the CPU checker's rejection applied to it."""
     w, h = 640, 400
     a, b = synth.shifted_pair(w, h, 3, -2, seed=11)
