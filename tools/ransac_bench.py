@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import synth as tsynth
 from feature_tracker_amd import device as D
+if os.environ.get("FT_EXP_LIB"):   # an experimental build of the device library
+    D.LIB_PATH = os.path.abspath(os.environ["FT_EXP_LIB"])
 calib = np.array([458.7, 457.3, 367.2, 248.4, 0, 0, 0, 0.0])
 ctx = D.DeviceContext(64, 64, max_levels=1, n_streams=1, n_slots=1, max_points=64 * 200, max_grid_cells=4, max_per_cell=2)
 for label, n_out, cal in (("1% outliers", 2, calib), ("30% outliers", 45, calib), ("1% outliers, distorted", 2, calib + np.array([0, 0, 0, 0, -0.28, 0.07, 1e-4, 1e-5]))):
