@@ -101,12 +101,6 @@ __device__ inline int ro_hypotheses_needed(int inliers, int n, int max_h) {
     return N;
 }
 
-// element j of a nine-element register array (a macro on purpose: behind a function boundary the compiler turns the
-// select chain into an indexed load and the array moves to scratch memory)
-#define RO_PICK9(v, j)                                                                                              \
-    ((j) == 8 ? (v)[8] : (j) == 7 ? (v)[7] : (j) == 6 ? (v)[6] : (j) == 5 ? (v)[5] : (j) == 4 ? (v)[4] : (j) == 3 ? (v)[3] \
-     : (j) == 2 ? (v)[2] : (j) == 1 ? (v)[1] : (v)[0])
-
 // T threads per workgroup: 256 (the usual job of a few hundred points: the latency of the dependent phases dominates)
 // or 512 (jobs of thousands of points, where the per-point phases dominate).  Hypotheses are always built by the first
 // 256 threads; everything per point is shared by all T.  The result does not depend on T.
@@ -172,6 +166,9 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
             uint32_t colmask = 0;
             bool row_used = false, ok = true;
             int my_pc = 0;
+            // Everything below is written without short-circuit operators, nested conditionals or lane-dependent
+            // branches: with them the compiler builds trees of divergent branches around the double-precision
+            // comparisons and selects, and the eight steps take 25 000 cycles instead of a third of that.
 #pragma unroll
             for (int step = 0; step < 8; step++) {
                 // largest remaining entry: first in this row, then across the eight rows (ties: lowest row, lowest column)
@@ -180,37 +177,61 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
                     const double v = fabs(A[j]);
-                    const bool take = !row_used && !((colmask >> j) & 1u) && v > bm;
+                    const bool take = (int)(!row_used) & (int)(!((colmask >> j) & 1u)) & (int)(v > bm);
                     bm = take ? v : bm;
                     brc = take ? ((r << 4) | j) : brc;
                 }
-#pragma unroll
-                for (int sft = 1; sft < 8; sft <<= 1) {
-                    const double om = __shfl_xor(bm, sft);
-                    const int orc = __shfl_xor(brc, sft);
-                    const bool take = om > bm || (om == bm && (orc >> 4) < (brc >> 4));
-                    bm = take ? om : bm;
-                    brc = take ? orc : brc;
+                // partner lanes r ^ 1, r ^ 2, then 7 - r (the other quad, whose four lanes agree by then): lane
+                // permutations inside a row of 16, no LDS round trip
+#define RO_PIVOT_ROUND(ctrl)                                                                                               \
+                {                                                                                                          \
+                    const uint64_t bb = __builtin_bit_cast(uint64_t, bm);                                                   \
+                    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)bb, ctrl, 0xF, 0xF, false);          \
+                    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(bb >> 32), ctrl, 0xF, 0xF, false);  \
+                    const int orc = __builtin_amdgcn_update_dpp(0, brc, ctrl, 0xF, 0xF, false);                            \
+                    const double om = __builtin_bit_cast(double, ((uint64_t)ohi << 32) | olo);                              \
+                    const bool take = (int)(om > bm) | ((int)(om == bm) & (int)((orc >> 4) < (brc >> 4)));                 \
+                    bm = take ? om : bm;                                                                                   \
+                    brc = take ? orc : brc;                                                                                \
                 }
-                if (!(bm >= 1e-12)) ok = false;   // same for the eight lanes; they run on (shuffles need all of them)
+                RO_PIVOT_ROUND(0xB1)    // quad_perm [1,0,3,2]
+                RO_PIVOT_ROUND(0x4E)    // quad_perm [2,3,0,1]
+                RO_PIVOT_ROUND(0x141)   // row_half_mirror
+#undef RO_PIVOT_ROUND
+                ok = (int)ok & (int)(bm >= 1e-12);   // same for the eight lanes; they run on (the exchanges need all of them)
                 const int pr = brc >> 4, pc = brc & 15;
                 double P[9];
 #pragma unroll
                 for (int j = 0; j < 9; j++) P[j] = __shfl(A[j], gbase | pr);
-                const double inv = 1. / RO_PICK9(P, pc);
-                const double mult = RO_PICK9(A, pc) * inv;
-                colmask |= 1u << pc;
-                if (r == pr) {
-                    row_used = true;
-                    my_pc = pc;
-                } else {
+                // entry pc of the pivot row and of this row, picked with bit masks
+                uint64_t ppc = 0, apc = 0;
 #pragma unroll
-                    for (int j = 0; j < 9; j++)
-                        if (!((colmask >> j) & 1u)) A[j] = A[j] - mult * P[j];
+                for (int j = 0; j < 9; j++) {
+                    const uint64_t m = j == pc ? ~0ull : 0ull;
+                    ppc |= __builtin_bit_cast(uint64_t, P[j]) & m;
+                    apc |= __builtin_bit_cast(uint64_t, A[j]) & m;
+                }
+                const double inv = 1. / __builtin_bit_cast(double, ppc);
+                const double mult = __builtin_bit_cast(double, apc) * inv;
+                colmask |= 1u << pc;
+                const bool is_pivot_row = r == pr;
+                row_used = (int)row_used | (int)is_pivot_row;
+                my_pc = is_pivot_row ? pc : my_pc;
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const double upd = A[j] - mult * P[j];
+                    const bool keep = (int)is_pivot_row | (int)((colmask >> j) & 1u);
+                    A[j] = keep ? A[j] : upd;
                 }
             }
             const int free_col = __builtin_ctz(~colmask & 0x1ffu);
-            const double y = -RO_PICK9(A, free_col) / RO_PICK9(A, my_pc);
+            uint64_t afree = 0, apiv = 0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                afree |= __builtin_bit_cast(uint64_t, A[j]) & (j == free_col ? ~0ull : 0ull);
+                apiv |= __builtin_bit_cast(uint64_t, A[j]) & (j == my_pc ? ~0ull : 0ull);
+            }
+            const double y = -__builtin_bit_cast(double, afree) / __builtin_bit_cast(double, apiv);
             Fs[hl][my_pc] = y;
             if (r == 0) {
                 Fs[hl][free_col] = 1.;
@@ -277,7 +298,5 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
         }
     }
 }
-
-#undef RO_PICK9
 
 }  // namespace ftd
