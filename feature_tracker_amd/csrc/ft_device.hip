@@ -735,7 +735,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     }
 
     size_t total = 0;
-    bool want_iters = false, stereo = false;
+    bool want_iters = false, stereo = false, need_guess = false;
     for (int j = 0; j < n_jobs; j++) {
         const ft_lk_job& J = jobs[j];
         if (J.n < 0) return FT_E_INVALID;
@@ -744,6 +744,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         total += (size_t)J.n;
         if (J.iters) want_iters = true;
         if (J.stereo_Rt && J.n > 0) stereo = true;
+        if (J.n > 0 && (!J.H || J.stereo_Rt)) need_guess = true;
     }
     const bool count_work = (c->profile & 2) != 0;
     if (count_work) want_iters = true;   // the counters come from the per-level iteration table
@@ -785,7 +786,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         for (int i = 0; i < J.n; i++) ptjob[off + i] = (uint16_t)j;
         if (J.n) {
             memcpy(pxy + 2 * off, J.prev_xy, 8 * (size_t)J.n);
-            memcpy(nxy + 2 * off, J.next_xy, 8 * (size_t)J.n);
+            if (need_guess) memcpy(nxy + 2 * off, J.next_xy, 8 * (size_t)J.n);
         }
         off += (size_t)J.n;
     }
@@ -797,7 +798,8 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     const bool direct_in = N <= 1024 && !stereo && !reject;
     const uint8_t* ib = direct_in ? c->lk_in_host_dev : c->lk_in_dev;
     if (!direct_in) {
-        const int n16 = (int)((off_next + 8 * N + 15) / 16);
+        // (every job seeded by its homography: the kernel never looks at the guesses, and they stay behind)
+        const int n16 = (int)(((need_guess ? off_next : off_prev) + 8 * N + 15) / 16);
         hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, enq(c), reinterpret_cast<const uint4*>(c->lk_in_host_dev),
                            reinterpret_cast<uint4*>(c->lk_in_dev), n16);
     }
@@ -807,7 +809,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.jobs = reinterpret_cast<const LKJobDev*>(ib);
     a.pt_job = reinterpret_cast<const uint16_t*>(ib + off_ptjob);
     a.prev_xy = reinterpret_cast<const float*>(ib + off_prev);
-    a.guess_xy = reinterpret_cast<const float*>(ib + off_next);
+    a.guess_xy = reinterpret_cast<const float*>(ib + (need_guess ? off_next : off_prev));   // read by every wave, used or not
     // Without a backward pass (which reads the forward results on the device) and without iteration counters, lane 0
     // of every wave writes its 13 result bytes straight into the pinned host block: no copy command to enqueue.
     const bool direct_out = !fb && !want_iters && !reject && !stereo;
