@@ -198,6 +198,15 @@ __device__ __forceinline__ uint32_t pack_lo16(int second, int first) {
     return __builtin_amdgcn_perm((uint32_t)second, (uint32_t)first, 0x05040100u);
 }
 
+// integer part of a position that is the same in all lanes, in a scalar register.  (The empty statement hides where
+// the value comes from: where the compiler can prove it uniform it drops the readfirstlane and then does the bounds
+// checks that follow with vector compares on the vector copy.)
+__device__ __forceinline__ int lk_uniform_floor(float v) {
+    int vi = (int)floorf(v);
+    asm("" : "+v"(vi));
+    return __builtin_amdgcn_readfirstlane(vi);
+}
+
 // ---- image regions in LDS ----
 struct Region {
     int rx0, ry0;     // image coordinates of the region origin (rx0 is a multiple of 4)
@@ -408,19 +417,34 @@ __device__ __forceinline__ void scharr_row_blend(const uint32_t (&U)[SEGLEN / 2 
     }
 }
 
-// SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more staged rows per lane)
-template <int SEGLEN, bool TALL>
-__global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
-    constexpr int WH_MAX = TALL ? 32 : 21;
-    constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
-    constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
-    constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
-    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
-    __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region (+ a row for the staging's surplus rows, + slack: row reads are dword-granular)
-    __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: window + Scharr apron
-    const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
-    if (pt >= a.total) return;
-    const int lane = threadIdx.x;
+// ---- what a wavefront works out once (LkWave), what it loads for its feature (LkPoint), and a level's geometry ----
+template <int SEGLEN> struct LkWave {
+    int lane, ww, wh, r, s, x0, rc, ext_w, reach_w, reach_h, n_valid;
+    bool row_ok;
+    float half_x, half_y, eps_f, eps_band, inv_area, min_eig_f;
+    uint32_t keep[SEGLEN / 2];
+};
+struct LkPoint {
+    float tx, ty;        // template point, level-0 coordinates
+    float gx0, gy0;      // first guess
+    bool use_init;
+    int img_I, img_J;    // linear slot indices of the template and the target pyramid
+    int w0, h0;          // level-0 size
+};
+// local names for the members of a LkWave (the blocks below were written against these names)
+#define LK_WAVE_LOCALS(W)                                                                                                  \
+    const int lane = (W).lane, ww = (W).ww, wh = (W).wh, r = (W).r, s = (W).s, x0 = (W).x0, rc = (W).rc, ext_w = (W).ext_w, \
+              reach_w = (W).reach_w, reach_h = (W).reach_h, n_valid = (W).n_valid;                                         \
+    const bool row_ok = (W).row_ok;                                                                                        \
+    const float half_x = (W).half_x, half_y = (W).half_y, eps_f = (W).eps_f, eps_band = (W).eps_band, inv_area = (W).inv_area, \
+                min_eig_f = (W).min_eig_f;                                                                                 \
+    const uint32_t(&keep)[SEGLEN / 2] = (W).keep;                                                                          \
+    constexpr float FLT_SCALE = 1.f / (1 << 20);                                                                           \
+    (void)lane; (void)ww; (void)wh; (void)r; (void)s; (void)x0; (void)rc; (void)ext_w; (void)reach_w; (void)reach_h; (void)n_valid; \
+    (void)row_ok; (void)half_x; (void)half_y; (void)eps_f; (void)eps_band; (void)inv_area; (void)min_eig_f; (void)keep; (void)FLT_SCALE;
+
+template <int SEGLEN>
+__device__ __forceinline__ void lk_prologue(const LKArgs& a, int pt, int lane, LkWave<SEGLEN>& W, LkPoint& P) {
     const int ww = a.win_w, wh = a.win_h;
     const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
     const int x0 = s * SEGLEN;
@@ -469,299 +493,374 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         }
     }
 
-    float outx = gx0, outy = gy0;   // nextPts[i]
-    int st = 1;
-    float errv = 0.f;
-    const float FLT_SCALE = 1.f / (1 << 20);
     const float eps_f = (float)a.epsilon, eps_band = eps_f * 1e-4f + 1e-30f;
     const float inv_area = 1.f / (float)(2 * ww * wh), min_eig_f = (float)a.min_eig;
+    W.lane = lane; W.ww = ww; W.wh = wh; W.r = r; W.s = s; W.x0 = x0; W.rc = rc; W.ext_w = ext_w; W.reach_w = reach_w; W.reach_h = reach_h;
+    W.n_valid = n_valid; W.row_ok = row_ok; W.half_x = half_x; W.half_y = half_y; W.eps_f = eps_f; W.eps_band = eps_band;
+    W.inv_area = inv_area; W.min_eig_f = min_eig_f;
+#pragma unroll
+    for (int m = 0; m < SEGLEN / 2; m++) W.keep[m] = keep[m];
+    P.tx = tx; P.ty = ty; P.gx0 = gx0; P.gy0 = gy0; P.use_init = use_init; P.img_I = img_I; P.img_J = img_J; P.w0 = w0; P.h0 = h0;
+}
+
+// size, positions and images of one level; advances the running estimate (outx, outy) to this level's scale
+struct LkLevel {
+    int w, h;
+    float px, py;        // template window corner (sub-pixel), this level
+    float nx, ny;        // target window corner at the start of the level
+    int ipx, ipy;        // integer part of (px, py)
+    bool tmpl_out;       // the template window lies outside the image
+    uint32_t ipitch;
+    const uint8_t* imgI;
+    const uint8_t* imgJ;
+};
+template <int SEGLEN>
+__device__ __forceinline__ LkLevel lk_level(const LKArgs& a, const LkWave<SEGLEN>& W, const LkPoint& P, int level, float& outx, float& outy) {
+    LkLevel G;
+    int w = P.w0, h = P.h0;
+    for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
+    const float scale = __builtin_bit_cast(float, (uint32_t)(127 - level) << 23);   // 2^-level
+    float px = P.tx * scale, py = P.ty * scale;
+    float nx, ny;
+    if (level == a.max_level) {
+        if (P.use_init) { nx = outx * scale; ny = outy * scale; }
+        else { nx = px; ny = py; }
+    } else {
+        nx = outx * 2.f; ny = outy * 2.f;
+    }
+    outx = nx; outy = ny;
+    px -= W.half_x; py -= W.half_y;
+    // positions are identical in all lanes: keep the integer parts in scalar registers
+    G.ipx = lk_uniform_floor(px); G.ipy = lk_uniform_floor(py);
+    G.tmpl_out = G.ipx < -W.ww || G.ipx >= w || G.ipy < -W.wh || G.ipy >= h;
+    G.w = w; G.h = h; G.px = px; G.py = py; G.nx = nx - W.half_x; G.ny = ny - W.half_y;
+    G.ipitch = a.A.lv[level].img_pitch;
+    G.imgI = level_img(a.A, P.img_I, level);
+    G.imgJ = level_img(a.A, P.img_J, level);
+    return G;
+}
+
+// The template of a level from the staged I region RI: per-lane samples Cw, gradient pairs GX / GY, the 2x2 matrix.
+template <int SEGLEN, bool TALL>
+__device__ __forceinline__ void lk_template(const LkWave<SEGLEN>& W, const uint32_t* __restrict__ ilds, const Region& RI, float px, float py, int ipx,
+                                            int ipy, int w, int h, int (&Cw)[SEGLEN], uint32_t (&GX)[SEGLEN / 2], uint32_t (&GY)[SEGLEN / 2],
+                                            float& A11, float& A12, float& A22) {
+    LK_WAVE_LOCALS(W)
+    constexpr int WH_MAX = TALL ? 32 : 21;
+    constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
+    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
+    // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
+    // Kept for the iterations: Cw[k] = 256 - 512 * I(k) (folds the subtraction of the template sample into the
+    // accumulator of the target blend), and the gradients as pairs GX[m] = (Ix(2m), Ix(2m+1)), GY[m] likewise.
+    {
+        const BilinW bw = bilin_weights(px - ipx, py - ipy);
+        const uint32_t wtop = (uint32_t)bw.w00 | ((uint32_t)bw.w01 << 16), wbot = (uint32_t)bw.w10 | ((uint32_t)bw.w11 << 16);
+        int sX[SEGLEN], sY[SEGLEN];
+#pragma unroll
+        for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
+        const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
+        uint32_t Rb[NP], Rc[NP];   // pixel pairs of the two rows the lane's template samples blend (old path: read below)
+        if constexpr (SEGLEN == 8 && !TALL) {
+            // Two steps through LDS.  (1) The integer Scharr gradients of the (wh + 1) x (ww + 1) patch are computed
+            // once, a half row of 12 columns per lane (22 x 2 tasks for 21 x 21), instead of 2.6 times over in the
+            // lanes that blend them; (2) every lane blends its eight samples from two rows of that patch.
+            constexpr int GP = 19;                               // dwords per patch row (pairs of columns), odd
+            __shared__ uint32_t gxl[(WH_MAX + 1) * GP], gyl[(WH_MAX + 1) * GP];
+            const int tpr = (ww + 1 + 11) / 12;                  // tasks per patch row
+            const int n_tasks = (wh + 1) * tpr;
+            for (int task = lane; task < n_tasks; task += 64) {
+                const int ra = tpr == 2 ? task >> 1 : (tpr == 1 ? task : task / 3), ha = task - ra * tpr;
+                const int boffA = ipx - 1 - RI.rx0 + 12 * ha;    // byte 0: image column ipx + 12 ha - 1
+                uint32_t U[7], M[7], L[7];
+                read_row_pairs_even<7, LK_PITCH>(ilds, ra, boffA, U);
+                read_row_pairs_even<7, LK_PITCH>(ilds, ra + 1, boffA, M);
+                read_row_pairs_even<7, LK_PITCH>(ilds, ra + 2, boffA, L);
+                lk_v2s T0[7], T1[7];
+#pragma unroll
+                for (int m = 0; m < 7; m++) {
+                    T0[m] = (v2s(U[m]) + v2s(L[m])) * (short)3 + v2s(M[m]) * (short)10;   // <= 4080
+                    T1[m] = v2s(L[m]) - v2s(U[m]);
+                }
+                const int gyA = ipy + ra, gxA = ipx + 12 * ha;
+                const bool row_in = gyA >= 0 && gyA < h;
+#pragma unroll
+                for (int m = 0; m < 6; m++) {                    // patch columns 12 ha + 2 m, + 1
+                    uint32_t px = u32(T0[m + 1] - T0[m]);
+                    const lk_v2s mid = v2s(next_pair(u32(T1[m + 1]), u32(T1[m])));
+                    uint32_t py = u32((T1[m] + T1[m + 1]) * (short)3 + mid * (short)10);
+                    if (!inside) {                               // the derivative image is zero outside the image
+                        const int gx = gxA + 2 * m;
+                        const uint32_t in = ((row_in && gx >= 0 && gx < w) ? 0xffffu : 0u) | ((row_in && gx + 1 >= 0 && gx + 1 < w) ? 0xffff0000u : 0u);
+                        px &= in; py &= in;
+                    }
+                    gxl[ra * GP + 6 * ha + m] = px;
+                    gyl[ra * GP + 6 * ha + m] = py;
+                }
+            }
+            lds_fence();
+            // the lane's samples k = 0..7 are patch columns x0 + k, x0 + k + 1 of patch rows rc, rc + 1
+            {
+                const uint32_t* ga = &gxl[rc * GP + 4 * s];
+                const uint32_t* gb = &gyl[rc * GP + 4 * s];
+                uint32_t xa[5], xb[5], ya[5], yb[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) { xa[q] = ga[q]; xb[q] = ga[GP + q]; ya[q] = gb[q]; yb[q] = gb[GP + q]; }
+#pragma unroll
+                for (int k = 0; k < SEGLEN; k++) {
+                    const int q = k >> 1;
+                    const uint32_t pxa = (k & 1) ? next_pair(xa[q + 1], xa[q]) : xa[q], pxb = (k & 1) ? next_pair(xb[q + 1], xb[q]) : xb[q];
+                    const uint32_t pya = (k & 1) ? next_pair(ya[q + 1], ya[q]) : ya[q], pyb = (k & 1) ? next_pair(yb[q + 1], yb[q]) : yb[q];
+                    sX[k] = dot2_acc(pxb, wbot, dot2_to_uniform(pxa, wtop, 1 << 13));   // 1 << 13: rounding term of the 14-bit descale
+                    sY[k] = dot2_acc(pyb, wbot, dot2_to_uniform(pya, wtop, 1 << 13));
+                }
+            }
+            // pixel pairs for the template samples: region rows rc + 1, rc + 2, from image column ipx + x0 - 1
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, ipx + x0 - 1 - RI.rx0, Rb);
+            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, ipx + x0 - 1 - RI.rx0, Rc);
+        } else {
+        // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
+        // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
+        const int boff = ipx + x0 - 1 - RI.rx0;
+        uint32_t Ra[NP], Rd[NP];
+        read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
+        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
+        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
+        const int gy = ipy + rc;
+        // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
+        // (the column passes through an opaque assembly statement inside the border branch: otherwise the compiler
+        // hoists the border masks' comparisons above the branch and every window pays for them)
+        if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
+        else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, col0, w); }
+        __builtin_amdgcn_sched_barrier(0);
+        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 3, boff, Rd);
+        if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
+        else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, col0, w); }
+        __builtin_amdgcn_sched_barrier(0);
+        }
+        int a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+        for (int m = 0; m < SEGLEN / 2; m++) {
+            GX[m] = pack_lo16(sX[2 * m + 1] >> 14, sX[2 * m] >> 14) & keep[m];
+            GY[m] = pack_lo16(sY[2 * m + 1] >> 14, sY[2 * m] >> 14) & keep[m];
+            a11 = m == 0 ? dot2_to_zero(GX[m], GX[m]) : dot2_acc(GX[m], GX[m], a11);
+            a12 = m == 0 ? dot2_to_zero(GX[m], GY[m]) : dot2_acc(GX[m], GY[m], a12);
+            a22 = m == 0 ? dot2_to_zero(GY[m], GY[m]) : dot2_acc(GY[m], GY[m], a22);
+        }
+#pragma unroll
+        for (int k = 0; k < SEGLEN; k++) {
+            // sample k blends pixel columns c = k+1, k+2 of region rows rc+1, rc+2
+            const uint32_t pb = (k & 1) ? Rb[(k + 1) / 2] : next_pair(Rb[k / 2 + 1], Rb[k / 2]);
+            const uint32_t pc = (k & 1) ? Rc[(k + 1) / 2] : next_pair(Rc[k / 2 + 1], Rc[k / 2]);
+            const int iw = dot2_acc(pc, wbot, dot2_to(pb, wtop, 256)) >> 9;
+            Cw[k] = 256 - (iw << 9);
+        }
+        wave_sum_exact3(a11, a22, a12, A11, A22, A12);
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+    }
+}
+
+// The smaller eigenvalue of the matrix against the threshold, and its determinant: 0 = the level can be tracked,
+// 2 = flat or degenerate template.  The eigenvalue's value is a result only when the caller asks for it (level 0,
+// eig_value); otherwise only the outcome of the comparison counts, and the hardware's square root and a reciprocal
+// multiply (together within 1e-6 of the trace over the area, relative) decide it whenever the value is clear of the
+// threshold by four times that; the correctly rounded square root and division run only in that band.
+template <int SEGLEN>
+__device__ __forceinline__ int lk_matrix_test(const LKArgs& a, const LkWave<SEGLEN>& W, int level, float A11, float A12, float A22, float& eig_value) {
+    const float D = A11 * A22 - A12 * A12;
+    const float eig_tr = A22 + A11, eig_disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+    bool eig_low;
+    const float approx = (eig_tr - __builtin_amdgcn_sqrtf(eig_disc)) * W.inv_area;
+    const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward;
+    if (!want_value && fabsf(approx - W.min_eig_f) > (eig_tr * W.inv_area + W.min_eig_f) * 4e-6f) {
+        eig_low = approx < W.min_eig_f;
+    } else {
+        const float minEig = (eig_tr - sqrtf(eig_disc)) / (float)(2 * W.ww * W.wh);
+        eig_value = minEig;
+        eig_low = (double)minEig < a.min_eig;
+    }
+    return (eig_low || D < 1.1920928955078125e-07f) ? 2 : 0;
+}
+
+// Newton iterations of one level on the staged J region R (re-staged when the window walks out of it), the per-level
+// iteration count, and at level 0 the residual at the final position.
+template <int SEGLEN, bool TALL>
+__device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEGLEN>& W, int pt, int level, uint32_t* __restrict__ jlds,
+                                               const uint8_t* __restrict__ imgJ, uint32_t ipitch, int w, int h, const int (&Cw)[SEGLEN],
+                                               const uint32_t (&GX)[SEGLEN / 2], const uint32_t (&GY)[SEGLEN / 2], float A11, float A12, float A22,
+                                               Region& R, float nx, float ny, float& outx, float& outy, int& st, float& errv) {
+    LK_WAVE_LOCALS(W)
+    constexpr int WH_MAX = TALL ? 32 : 21;
+    constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
+    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
+    float D = A11 * A22 - A12 * A12;
+    D = 1.f / D;
+    int n_iter;
+    // ---- Newton iterations on the target image, fed from LDS ----
+    float pdx = 0.f, pdy = 0.f;
+    n_iter = 0;
+    for (int j = 0; j < a.max_iter; j++) {
+        const int inx = lk_uniform_floor(nx), iny = lk_uniform_floor(ny);
+        if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
+            if (level == 0) st = 0;
+            break;
+        }
+        n_iter = j + 1;
+        if (!region_holds(R, inx, iny, ext_w, wh)) {
+            R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+            lds_fence();
+        }
+        const BilinW jw = bilin_weights(nx - inx, ny - iny);
+        const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
+        uint32_t p0[SEGLEN], p1[SEGLEN];
+        const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
+        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
+        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
+        int b1 = 0, b2 = 0;
+#pragma unroll
+        for (int m = 0; m < SEGLEN / 2; m++) {
+            const int d0 = dot2_acc(p1[2 * m], wbot, dot2_to(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
+            const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_to(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
+            const uint32_t dp = pack_lo16(d1, d0);
+            b1 = m == 0 ? dot2_to_zero(dp, GX[m]) : dot2_acc(dp, GX[m], b1);
+            b2 = m == 0 ? dot2_to_zero(dp, GY[m]) : dot2_acc(dp, GY[m], b2);
+        }
+        float fb1, fb2;
+        wave_sum_exact2(b1, b2, fb1, fb2);
+        fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
+        const float dx = (A12 * fb2 - A22 * fb1) * D;
+        const float dy = (A12 * fb1 - A11 * fb2) * D;
+        nx += dx; ny += dy;
+        outx = nx + half_x; outy = ny + half_y;
+        // delta . delta <= epsilon in double precision, as the reference computes it.  The float value decides
+        // whenever it is clear of the bound by far more than its rounding error (a few 1e-7 relative); the double
+        // arithmetic, at half the issue rate, runs only in the band around the bound.  Uniform for the wave.
+        {
+            const float s = dx * dx + dy * dy;
+            const bool far = fabsf(s - eps_f) > eps_band;
+            if (far ? s < eps_f : (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
+        }
+        // |dx + pdx| < 0.01 and |dy + pdy| < 0.01 in double precision: for a float, "< 0.01" is "< the float above 0.01"
+        if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
+            outx -= dx * 0.5f; outy -= dy * 0.5f;
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+    if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+
+    // ---- residual at the final position (level 0 only) ----
+    if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
+        const float qx = outx - half_x, qy = outy - half_y;
+        const int iqx = lk_uniform_floor(qx), iqy = lk_uniform_floor(qy);
+        if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
+            st = 0;
+        } else if (!(a.flags & FT_LK_NO_ERROR)) {
+            if (!region_holds(R, iqx, iqy, ext_w, wh)) {
+                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+                lds_fence();
+            }
+            const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
+            const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
+            uint32_t p0[SEGLEN], p1[SEGLEN];
+            const int boff = iqx - R.rx0 + x0, row = iqy - R.ry0 + rc;
+            read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
+            read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < SEGLEN; k++) {
+                const int diff = dot2_acc(p1[k], wbot, dot2_to(p0[k], wtop, Cw[k])) >> 9;
+                if (k < n_valid) e += abs(diff);
+            }
+            const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
+            errv = errsum * 1.f / (float)(32 * ww * wh);
+        }
+    }
+}
+
+__device__ __forceinline__ void lk_write_result(const LKArgs& a, int pt, const LkPoint& P, float outx, float outy, int st, float errv) {
+    if (!a.backward) {
+        a.next_xy[2 * pt] = outx;
+        a.next_xy[2 * pt + 1] = outy;
+        a.status[pt] = (uint8_t)st;
+        a.err[pt] = errv;
+    } else {
+        // forward-backward consistency: the backward track must succeed and return to the original point
+        const float dx = outx - P.gx0, dy = outy - P.gy0;
+        const float d2 = dx * dx + dy * dy;
+        if (!st || !(d2 <= a.fb_thresh2)) a.status[pt] = 0;
+    }
+}
+#undef LK_WAVE_LOCALS
+
+// One wavefront per feature.  SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more staged rows per lane)
+template <int SEGLEN, bool TALL>
+__global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
+    constexpr int WH_MAX = TALL ? 32 : 21;
+    constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
+    constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
+    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
+    __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region (+ a row for the staging's surplus rows, + slack: row reads are dword-granular)
+    __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: window + Scharr apron
+    const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
+    if (pt >= a.total) return;
+    const int lane = threadIdx.x;
+    LkWave<SEGLEN> W;
+    LkPoint P;
+    lk_prologue<SEGLEN>(a, pt, lane, W, P);
+    float outx = P.gx0, outy = P.gy0;   // nextPts[i]
+    int st = 1;
+    float errv = 0.f;
 
     for (int level = a.max_level; level >= 0; level--) {
-        int w = w0, h = h0;
-        for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
-        const float scale = __builtin_bit_cast(float, (uint32_t)(127 - level) << 23);   // 2^-level
-        float px = tx * scale, py = ty * scale;
-        float nx, ny;
-        if (level == a.max_level) {
-            if (use_init) { nx = outx * scale; ny = outy * scale; }
-            else { nx = px; ny = py; }
-        } else {
-            nx = outx * 2.f; ny = outy * 2.f;
-        }
-        outx = nx; outy = ny;
-        int n_iter = -1;
-
-        px -= half_x; py -= half_y;
-        // positions are identical in all lanes: keep the integer parts in scalar registers
-        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
-        if (ipx < -ww || ipx >= w || ipy < -wh || ipy >= h) {
+        const LkLevel G = lk_level<SEGLEN>(a, W, P, level, outx, outy);
+        if (G.tmpl_out) {
             if (level == 0) { st = 0; errv = 0.f; }
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             continue;
         }
-
         // ---- stage both regions of this level: their loads are in flight together ----
-        const uint32_t ipitch = a.A.lv[level].img_pitch;
-        const uint8_t* imgI = level_img(a.A, img_I, level);
-        const uint8_t* imgJ = level_img(a.A, img_J, level);
-        nx -= half_x; ny -= half_y;
-        const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-        Region RI = region_of(ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3);
-        Region R = region_of(inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN);
-        if (region_cols_inside(RI, w) && region_cols_inside(R, w) && h >= reach_h && !(iny0 < -wh || iny0 >= h)) {
+        const int w = G.w, h = G.h;
+        const int inx0 = lk_uniform_floor(G.nx), iny0 = lk_uniform_floor(G.ny);
+        Region RI = region_of(G.ipx - 1, G.ipx + W.ext_w + 1, G.ipy - 1, W.wh + 3);
+        Region R = region_of(inx0 - LK_MARGIN, inx0 + W.ext_w + LK_MARGIN, iny0 - LK_MARGIN, W.wh + 1 + 2 * LK_MARGIN);
+        if (region_cols_inside(RI, w) && region_cols_inside(R, w) && h >= W.reach_h && !(iny0 < -W.wh || iny0 >= h)) {
             // the usual case: one memory round trip for both regions and no byte shuffling; rows outside the image
             // (regions near the upper or lower border) are read from their mirror rows
             LkInteriorRows<I_ROWS> vi;
             LkInteriorRows<J_ROWS> vj;
             if (region_rows_inside(RI, h) && region_rows_inside(R, h)) {
-                load_interior<I_ROWS, true>(vi, imgI, ipitch, h, RI, lane);
-                load_interior<J_ROWS, true>(vj, imgJ, ipitch, h, R, lane);
+                load_interior<I_ROWS, true>(vi, G.imgI, G.ipitch, h, RI, lane);
+                load_interior<J_ROWS, true>(vj, G.imgJ, G.ipitch, h, R, lane);
             } else {
-                load_interior<I_ROWS, false>(vi, imgI, ipitch, h, RI, lane);
-                load_interior<J_ROWS, false>(vj, imgJ, ipitch, h, R, lane);
+                load_interior<I_ROWS, false>(vi, G.imgI, G.ipitch, h, RI, lane);
+                load_interior<J_ROWS, false>(vj, G.imgJ, G.ipitch, h, R, lane);
             }
             store_interior<I_ROWS, LK_PITCH>(ilds, vi, lane);
             store_interior<J_ROWS, LK_PITCH>(jlds, vj, lane);
         } else {
-            RI = stage_region<I_ROWS, LK_PITCH>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
+            RI = stage_region<I_ROWS, LK_PITCH>(ilds, G.imgI, G.ipitch, w, h, G.ipx - 1, G.ipx + W.ext_w + 1, G.ipy - 1, W.wh + 3, lane, W.reach_w, W.reach_h);
             R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
-            if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h))
-                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+            if (!(inx0 < -W.ww || inx0 >= w || iny0 < -W.wh || iny0 >= h))
+                R = stage_region<J_ROWS, LK_PITCH>(jlds, G.imgJ, G.ipitch, w, h, inx0 - LK_MARGIN, inx0 + W.ext_w + LK_MARGIN, iny0 - LK_MARGIN, W.wh + 1 + 2 * LK_MARGIN, lane, W.reach_w, W.reach_h);
         }
         lds_fence();
 
-        // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
-        // Kept for the iterations: Cw[k] = 256 - 512 * I(k) (folds the subtraction of the template sample into the
-        // accumulator of the target blend), and the gradients as pairs GX[m] = (Ix(2m), Ix(2m+1)), GY[m] likewise.
         int Cw[SEGLEN];
         uint32_t GX[SEGLEN / 2], GY[SEGLEN / 2];
         float A11, A12, A22;
-        {
-            const BilinW bw = bilin_weights(px - ipx, py - ipy);
-            const uint32_t wtop = (uint32_t)bw.w00 | ((uint32_t)bw.w01 << 16), wbot = (uint32_t)bw.w10 | ((uint32_t)bw.w11 << 16);
-            int sX[SEGLEN], sY[SEGLEN];
-#pragma unroll
-            for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
-            const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
-            uint32_t Rb[NP], Rc[NP];   // pixel pairs of the two rows the lane's template samples blend (old path: read below)
-            if constexpr (SEGLEN == 8 && !TALL) {
-                // Two steps through LDS.  (1) The integer Scharr gradients of the (wh + 1) x (ww + 1) patch are computed
-                // once, a half row of 12 columns per lane (22 x 2 tasks for 21 x 21), instead of 2.6 times over in the
-                // lanes that blend them; (2) every lane blends its eight samples from two rows of that patch.
-                constexpr int GP = 19;                               // dwords per patch row (pairs of columns), odd
-                __shared__ uint32_t gxl[(WH_MAX + 1) * GP], gyl[(WH_MAX + 1) * GP];
-                const int tpr = (ww + 1 + 11) / 12;                  // tasks per patch row
-                const int n_tasks = (wh + 1) * tpr;
-                for (int task = lane; task < n_tasks; task += 64) {
-                    const int ra = tpr == 2 ? task >> 1 : (tpr == 1 ? task : task / 3), ha = task - ra * tpr;
-                    const int boffA = ipx - 1 - RI.rx0 + 12 * ha;    // byte 0: image column ipx + 12 ha - 1
-                    uint32_t U[7], M[7], L[7];
-                    read_row_pairs_even<7, LK_PITCH>(ilds, ra, boffA, U);
-                    read_row_pairs_even<7, LK_PITCH>(ilds, ra + 1, boffA, M);
-                    read_row_pairs_even<7, LK_PITCH>(ilds, ra + 2, boffA, L);
-                    lk_v2s T0[7], T1[7];
-#pragma unroll
-                    for (int m = 0; m < 7; m++) {
-                        T0[m] = (v2s(U[m]) + v2s(L[m])) * (short)3 + v2s(M[m]) * (short)10;   // <= 4080
-                        T1[m] = v2s(L[m]) - v2s(U[m]);
-                    }
-                    const int gyA = ipy + ra, gxA = ipx + 12 * ha;
-                    const bool row_in = gyA >= 0 && gyA < h;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) {                    // patch columns 12 ha + 2 m, + 1
-                        uint32_t px = u32(T0[m + 1] - T0[m]);
-                        const lk_v2s mid = v2s(next_pair(u32(T1[m + 1]), u32(T1[m])));
-                        uint32_t py = u32((T1[m] + T1[m + 1]) * (short)3 + mid * (short)10);
-                        if (!inside) {                               // the derivative image is zero outside the image
-                            const int gx = gxA + 2 * m;
-                            const uint32_t in = ((row_in && gx >= 0 && gx < w) ? 0xffffu : 0u) | ((row_in && gx + 1 >= 0 && gx + 1 < w) ? 0xffff0000u : 0u);
-                            px &= in; py &= in;
-                        }
-                        gxl[ra * GP + 6 * ha + m] = px;
-                        gyl[ra * GP + 6 * ha + m] = py;
-                    }
-                }
-                lds_fence();
-                // the lane's samples k = 0..7 are patch columns x0 + k, x0 + k + 1 of patch rows rc, rc + 1
-                {
-                    const uint32_t* ga = &gxl[rc * GP + 4 * s];
-                    const uint32_t* gb = &gyl[rc * GP + 4 * s];
-                    uint32_t xa[5], xb[5], ya[5], yb[5];
-#pragma unroll
-                    for (int q = 0; q < 5; q++) { xa[q] = ga[q]; xb[q] = ga[GP + q]; ya[q] = gb[q]; yb[q] = gb[GP + q]; }
-#pragma unroll
-                    for (int k = 0; k < SEGLEN; k++) {
-                        const int q = k >> 1;
-                        const uint32_t pxa = (k & 1) ? next_pair(xa[q + 1], xa[q]) : xa[q], pxb = (k & 1) ? next_pair(xb[q + 1], xb[q]) : xb[q];
-                        const uint32_t pya = (k & 1) ? next_pair(ya[q + 1], ya[q]) : ya[q], pyb = (k & 1) ? next_pair(yb[q + 1], yb[q]) : yb[q];
-                        sX[k] = dot2_acc(pxb, wbot, dot2_to_uniform(pxa, wtop, 1 << 13));   // 1 << 13: rounding term of the 14-bit descale
-                        sY[k] = dot2_acc(pyb, wbot, dot2_to_uniform(pya, wtop, 1 << 13));
-                    }
-                }
-                // pixel pairs for the template samples: region rows rc + 1, rc + 2, from image column ipx + x0 - 1
-                read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, ipx + x0 - 1 - RI.rx0, Rb);
-                read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, ipx + x0 - 1 - RI.rx0, Rc);
-            } else {
-            // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
-            // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
-            const int boff = ipx + x0 - 1 - RI.rx0;
-            uint32_t Ra[NP], Rd[NP];
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
-            const int gy = ipy + rc;
-            // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
-            // (the column passes through an opaque assembly statement inside the border branch: otherwise the compiler
-            // hoists the border masks' comparisons above the branch and every window pays for them)
-            if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
-            else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, col0, w); }
-            __builtin_amdgcn_sched_barrier(0);
-            read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 3, boff, Rd);
-            if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
-            else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, col0, w); }
-            __builtin_amdgcn_sched_barrier(0);
-            }
-            int a11 = 0, a12 = 0, a22 = 0;
-#pragma unroll
-            for (int m = 0; m < SEGLEN / 2; m++) {
-                GX[m] = pack_lo16(sX[2 * m + 1] >> 14, sX[2 * m] >> 14) & keep[m];
-                GY[m] = pack_lo16(sY[2 * m + 1] >> 14, sY[2 * m] >> 14) & keep[m];
-                a11 = m == 0 ? dot2_to_zero(GX[m], GX[m]) : dot2_acc(GX[m], GX[m], a11);
-                a12 = m == 0 ? dot2_to_zero(GX[m], GY[m]) : dot2_acc(GX[m], GY[m], a12);
-                a22 = m == 0 ? dot2_to_zero(GY[m], GY[m]) : dot2_acc(GY[m], GY[m], a22);
-            }
-#pragma unroll
-            for (int k = 0; k < SEGLEN; k++) {
-                // sample k blends pixel columns c = k+1, k+2 of region rows rc+1, rc+2
-                const uint32_t pb = (k & 1) ? Rb[(k + 1) / 2] : next_pair(Rb[k / 2 + 1], Rb[k / 2]);
-                const uint32_t pc = (k & 1) ? Rc[(k + 1) / 2] : next_pair(Rc[k / 2 + 1], Rc[k / 2]);
-                const int iw = dot2_acc(pc, wbot, dot2_to(pb, wtop, 256)) >> 9;
-                Cw[k] = 256 - (iw << 9);
-            }
-            wave_sum_exact3(a11, a22, a12, A11, A22, A12);
-            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
-        }
-        float D = A11 * A22 - A12 * A12;
-        // The smaller eigenvalue against the threshold.  Its value is a result only when the caller asks for it (level
-        // 0); otherwise only the outcome of the comparison counts, and the hardware's square root and a reciprocal
-        // multiply (together within 1e-6 of the trace over the area, relative) decide it whenever the value is clear
-        // of the threshold by four times that; the correctly rounded square root and division run only in that band.
-        const float eig_tr = A22 + A11, eig_disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
-        bool eig_low;
-        {
-            const float approx = (eig_tr - __builtin_amdgcn_sqrtf(eig_disc)) * inv_area;
-            const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward;
-            if (!want_value && fabsf(approx - min_eig_f) > (eig_tr * inv_area + min_eig_f) * 4e-6f) {
-                eig_low = approx < min_eig_f;
-            } else {
-                const float minEig = (eig_tr - sqrtf(eig_disc)) / (float)(2 * ww * wh);
-                if (want_value) errv = minEig;
-                eig_low = (double)minEig < a.min_eig;
-            }
-        }
-        if (eig_low || D < 1.1920928955078125e-07f) {
+        lk_template<SEGLEN, TALL>(W, ilds, RI, G.px, G.py, G.ipx, G.ipy, w, h, Cw, GX, GY, A11, A12, A22);
+        float eig_value = 0.f;
+        const int code = lk_matrix_test<SEGLEN>(a, W, level, A11, A12, A22, eig_value);
+        if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = eig_value;
+        if (code != 0) {
             if (level == 0) st = 0;
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             continue;
         }
-        D = 1.f / D;
-
-        // ---- Newton iterations on the target image, fed from LDS ----
-        float pdx = 0.f, pdy = 0.f;
-        n_iter = 0;
-        for (int j = 0; j < a.max_iter; j++) {
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-            if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
-                if (level == 0) st = 0;
-                break;
-            }
-            n_iter = j + 1;
-            if (!region_holds(R, inx, iny, ext_w, wh)) {
-                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
-                lds_fence();
-            }
-            const BilinW jw = bilin_weights(nx - inx, ny - iny);
-            const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
-            uint32_t p0[SEGLEN], p1[SEGLEN];
-            const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
-            read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
-            read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
-            int b1 = 0, b2 = 0;
-#pragma unroll
-            for (int m = 0; m < SEGLEN / 2; m++) {
-                const int d0 = dot2_acc(p1[2 * m], wbot, dot2_to(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
-                const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_to(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
-                const uint32_t dp = pack_lo16(d1, d0);
-                b1 = m == 0 ? dot2_to_zero(dp, GX[m]) : dot2_acc(dp, GX[m], b1);
-                b2 = m == 0 ? dot2_to_zero(dp, GY[m]) : dot2_acc(dp, GY[m], b2);
-            }
-            float fb1, fb2;
-            wave_sum_exact2(b1, b2, fb1, fb2);
-            fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
-            const float dx = (A12 * fb2 - A22 * fb1) * D;
-            const float dy = (A12 * fb1 - A11 * fb2) * D;
-            nx += dx; ny += dy;
-            outx = nx + half_x; outy = ny + half_y;
-            // delta . delta <= epsilon in double precision, as the reference computes it.  The float value decides
-            // whenever it is clear of the bound by far more than its rounding error (a few 1e-7 relative); the double
-            // arithmetic, at half the issue rate, runs only in the band around the bound.  Uniform for the wave.
-            {
-                const float s = dx * dx + dy * dy;
-                const bool far = fabsf(s - eps_f) > eps_band;
-                if (far ? s < eps_f : (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
-            }
-            // |dx + pdx| < 0.01 and |dy + pdy| < 0.01 in double precision: for a float, "< 0.01" is "< the float above 0.01"
-            if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
-                outx -= dx * 0.5f; outy -= dy * 0.5f;
-                break;
-            }
-            pdx = dx; pdy = dy;
-        }
-        if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
-
-        // ---- residual at the final position (level 0 only) ----
-        if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
-            const float qx = outx - half_x, qy = outy - half_y;
-            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
-            if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
-                st = 0;
-            } else if (!(a.flags & FT_LK_NO_ERROR)) {
-                if (!region_holds(R, iqx, iqy, ext_w, wh)) {
-                    R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
-                    lds_fence();
-                }
-                const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
-                const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
-                uint32_t p0[SEGLEN], p1[SEGLEN];
-                const int boff = iqx - R.rx0 + x0, row = iqy - R.ry0 + rc;
-                read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
-                read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
-                int e = 0;
-#pragma unroll
-                for (int k = 0; k < SEGLEN; k++) {
-                    const int diff = dot2_acc(p1[k], wbot, dot2_to(p0[k], wtop, Cw[k])) >> 9;
-                    if (k < n_valid) e += abs(diff);
-                }
-                const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
-                errv = errsum * 1.f / (float)(32 * ww * wh);
-            }
-        }
+        lk_track_level<SEGLEN, TALL>(a, W, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
         __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
     }
-
-    if (lane == 0) {
-        if (!a.backward) {
-            a.next_xy[2 * pt] = outx;
-            a.next_xy[2 * pt + 1] = outy;
-            a.status[pt] = (uint8_t)st;
-            a.err[pt] = errv;
-        } else {
-            // forward-backward consistency: the backward track must succeed and return to the original point
-            const float dx = outx - gx0, dy = outy - gy0;
-            const float d2 = dx * dx + dy * dy;
-            if (!st || !(d2 <= a.fb_thresh2)) a.status[pt] = 0;
-        }
-    }
+    if (lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
 }
 
 // The same tracking with two wavefronts per feature.  The template of a level (staging of the I region, Scharr patch,
@@ -777,7 +876,6 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
-    constexpr int NP = SEGLEN / 2 + 2;                              // pixel pairs a lane reads per template row
     constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
     __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region: the tracker's
     __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: the templater's
@@ -788,84 +886,16 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     if (pt >= a.total) return;
     const int lane = threadIdx.x & 63;
     const bool templater = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) != 0;
-    const int ww = a.win_w, wh = a.win_h;
-    const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
-    const int x0 = s * SEGLEN;
-    const bool row_ok = r < wh;
-    const int rc = row_ok ? r : wh - 1;          // lanes below the window reuse its last row (results masked)
-    const int ext_w = a.segs * SEGLEN;           // columns the lanes touch: [0, ext_w]
-    const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
-    // smallest level size for which a staged region needs at most one reflection per axis (with some slack)
-    const int reach_w = ext_w + 2 * LK_MARGIN + 8, reach_h = wh + 2 * LK_MARGIN + 8;
-    // which of the lane's samples belong to the window: 16-bit masks for the packed (sample 2m, sample 2m+1) pairs
-    const int n_valid = row_ok ? min(max(ww - x0, 0), SEGLEN) : 0;
-    uint32_t keep[SEGLEN / 2];
-#pragma unroll
-    for (int m = 0; m < SEGLEN / 2; m++) keep[m] = (n_valid > 2 * m ? 0xffffu : 0u) | (n_valid > 2 * m + 1 ? 0xffff0000u : 0u);
-
-    // forward: template = prev pyramid at prev_xy, target = next pyramid, guess from guess_xy / H / prev
-    // backward: template = next pyramid at the forward result, target = prev pyramid, guess = original point
-    // Everything indexed by the point is loaded in one batch, then every field of the job record the kernel uses in a
-    // second one: a wave starts with two memory round trips behind the kernel arguments instead of one per field.
-    const float* t_src = a.backward ? a.next_xy : a.prev_xy;
-    const float* g_src = a.backward ? a.prev_xy : a.guess_xy;
-    const int job_i = a.pt_job[pt];
-    const float tx = t_src[2 * pt], ty = t_src[2 * pt + 1];
-    float gx0 = g_src[2 * pt], gy0 = g_src[2 * pt + 1];
-    const LKJobDev* job = a.jobs + job_i;
-    const int img_I = a.backward ? job->img_next : job->img_prev;
-    const int img_J = a.backward ? job->img_prev : job->img_next;
-    const int job_use_H = job->use_H, job_use_stereo = job->use_stereo;
-    float H[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) H[k] = job->H[k];
-    const int w0 = job->w0, h0 = job->h0;      // level-0 size (a load inside the level loop would be a round trip per level)
-    // (the empty statement uses all of them here, so that the loads are issued together rather than where a branch
-    // first needs each)
-    asm volatile("" ::"s"(img_I), "s"(img_J), "s"(job_use_H), "s"(job_use_stereo), "s"(w0), "s"(h0), "s"(H[0]), "s"(H[1]), "s"(H[2]), "s"(H[3]),
-                 "s"(H[4]), "s"(H[5]), "s"(H[6]), "s"(H[7]), "s"(H[8]));
-    bool use_init = true;
-    if (!a.backward) {
-        if (job_use_H) {
-            const float p0 = H[0] * tx + H[1] * ty + H[2];
-            const float p1 = H[3] * tx + H[4] * ty + H[5];
-            const float p2 = H[6] * tx + H[7] * ty + H[8];
-            gx0 = p0 / p2; gy0 = p1 / p2;
-        } else {
-            use_init = (a.flags & FT_LK_USE_INITIAL_FLOW) != 0 || job_use_stereo != 0;   // stereo guesses were written on the device
-        }
-    }
-
-    float outx = gx0, outy = gy0;   // nextPts[i]
+    LkWave<SEGLEN> W;
+    LkPoint P;
+    lk_prologue<SEGLEN>(a, pt, lane, W, P);
+    float outx = P.gx0, outy = P.gy0;   // nextPts[i]
     int st = 1;
     float errv = 0.f;
-    const float FLT_SCALE = 1.f / (1 << 20);
-    const float eps_f = (float)a.epsilon, eps_band = eps_f * 1e-4f + 1e-30f;
-    const float inv_area = 1.f / (float)(2 * ww * wh), min_eig_f = (float)a.min_eig;
 
     for (int level = a.max_level; level >= 0; level--) {
-        int w = w0, h = h0;
-        for (int l = 0; l < level; l++) { w = half_up(w); h = half_up(h); }
-        const float scale = __builtin_bit_cast(float, (uint32_t)(127 - level) << 23);   // 2^-level
-        float px = tx * scale, py = ty * scale;
-        float nx, ny;
-        if (level == a.max_level) {
-            if (use_init) { nx = outx * scale; ny = outy * scale; }
-            else { nx = px; ny = py; }
-        } else {
-            nx = outx * 2.f; ny = outy * 2.f;
-        }
-        outx = nx; outy = ny;
-        int n_iter = -1;
-
-        px -= half_x; py -= half_y;
-        // positions are identical in all lanes: keep the integer parts in scalar registers
-        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
-        const bool tmpl_out = ipx < -ww || ipx >= w || ipy < -wh || ipy >= h;
-        const uint32_t ipitch = a.A.lv[level].img_pitch;
-        const uint8_t* imgI = level_img(a.A, img_I, level);
-        const uint8_t* imgJ = level_img(a.A, img_J, level);
-        nx -= half_x; ny -= half_y;
+        const LkLevel G = lk_level<SEGLEN>(a, W, P, level, outx, outy);
+        const int w = G.w, h = G.h;
         Region R;
         R.rx0 = 0; R.ry0 = 0; R.rwd = 0; R.rh = 0;   // nothing staged yet
         int Cw[SEGLEN];
@@ -876,133 +906,11 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
         if (templater) {
             int code = 1;
             float eig_value = 0.f;
-            if (!tmpl_out) {
-                const Region RI = stage_region<I_ROWS, LK_PITCH>(ilds, imgI, ipitch, w, h, ipx - 1, ipx + ext_w + 1, ipy - 1, wh + 3, lane, reach_w, reach_h);
+            if (!G.tmpl_out) {
+                const Region RI = stage_region<I_ROWS, LK_PITCH>(ilds, G.imgI, G.ipitch, w, h, G.ipx - 1, G.ipx + W.ext_w + 1, G.ipy - 1, W.wh + 3, lane, W.reach_w, W.reach_h);
                 lds_fence();
-                // ---- template: bilinear samples of I (x32) and of its Scharr gradients, all from the staged region ----
-                // Kept for the iterations: Cw[k] = 256 - 512 * I(k) (folds the subtraction of the template sample into the
-                // accumulator of the target blend), and the gradients as pairs GX[m] = (Ix(2m), Ix(2m+1)), GY[m] likewise.
-                {
-                    const BilinW bw = bilin_weights(px - ipx, py - ipy);
-                    const uint32_t wtop = (uint32_t)bw.w00 | ((uint32_t)bw.w01 << 16), wbot = (uint32_t)bw.w10 | ((uint32_t)bw.w11 << 16);
-                    int sX[SEGLEN], sY[SEGLEN];
-        #pragma unroll
-                    for (int k = 0; k < SEGLEN; k++) { sX[k] = 1 << 13; sY[k] = 1 << 13; }   // rounding term of the 14-bit descale
-                    const bool inside = ipx >= 0 && ipx + ext_w < w && ipy >= 0 && ipy + wh < h;   // every gradient tap is in the image
-                    uint32_t Rb[NP], Rc[NP];   // pixel pairs of the two rows the lane's template samples blend (old path: read below)
-                    if constexpr (SEGLEN == 8 && !TALL) {
-                        // Two steps through LDS.  (1) The integer Scharr gradients of the (wh + 1) x (ww + 1) patch are computed
-                        // once, a half row of 12 columns per lane (22 x 2 tasks for 21 x 21), instead of 2.6 times over in the
-                        // lanes that blend them; (2) every lane blends its eight samples from two rows of that patch.
-                        constexpr int GP = 19;                               // dwords per patch row (pairs of columns), odd
-                        __shared__ uint32_t gxl[(WH_MAX + 1) * GP], gyl[(WH_MAX + 1) * GP];
-                        const int tpr = (ww + 1 + 11) / 12;                  // tasks per patch row
-                        const int n_tasks = (wh + 1) * tpr;
-                        for (int task = lane; task < n_tasks; task += 64) {
-                            const int ra = tpr == 2 ? task >> 1 : (tpr == 1 ? task : task / 3), ha = task - ra * tpr;
-                            const int boffA = ipx - 1 - RI.rx0 + 12 * ha;    // byte 0: image column ipx + 12 ha - 1
-                            uint32_t U[7], M[7], L[7];
-                            read_row_pairs_even<7, LK_PITCH>(ilds, ra, boffA, U);
-                            read_row_pairs_even<7, LK_PITCH>(ilds, ra + 1, boffA, M);
-                            read_row_pairs_even<7, LK_PITCH>(ilds, ra + 2, boffA, L);
-                            lk_v2s T0[7], T1[7];
-        #pragma unroll
-                            for (int m = 0; m < 7; m++) {
-                                T0[m] = (v2s(U[m]) + v2s(L[m])) * (short)3 + v2s(M[m]) * (short)10;   // <= 4080
-                                T1[m] = v2s(L[m]) - v2s(U[m]);
-                            }
-                            const int gyA = ipy + ra, gxA = ipx + 12 * ha;
-                            const bool row_in = gyA >= 0 && gyA < h;
-        #pragma unroll
-                            for (int m = 0; m < 6; m++) {                    // patch columns 12 ha + 2 m, + 1
-                                uint32_t px = u32(T0[m + 1] - T0[m]);
-                                const lk_v2s mid = v2s(next_pair(u32(T1[m + 1]), u32(T1[m])));
-                                uint32_t py = u32((T1[m] + T1[m + 1]) * (short)3 + mid * (short)10);
-                                if (!inside) {                               // the derivative image is zero outside the image
-                                    const int gx = gxA + 2 * m;
-                                    const uint32_t in = ((row_in && gx >= 0 && gx < w) ? 0xffffu : 0u) | ((row_in && gx + 1 >= 0 && gx + 1 < w) ? 0xffff0000u : 0u);
-                                    px &= in; py &= in;
-                                }
-                                gxl[ra * GP + 6 * ha + m] = px;
-                                gyl[ra * GP + 6 * ha + m] = py;
-                            }
-                        }
-                        lds_fence();
-                        // the lane's samples k = 0..7 are patch columns x0 + k, x0 + k + 1 of patch rows rc, rc + 1
-                        {
-                            const uint32_t* ga = &gxl[rc * GP + 4 * s];
-                            const uint32_t* gb = &gyl[rc * GP + 4 * s];
-                            uint32_t xa[5], xb[5], ya[5], yb[5];
-        #pragma unroll
-                            for (int q = 0; q < 5; q++) { xa[q] = ga[q]; xb[q] = ga[GP + q]; ya[q] = gb[q]; yb[q] = gb[GP + q]; }
-        #pragma unroll
-                            for (int k = 0; k < SEGLEN; k++) {
-                                const int q = k >> 1;
-                                const uint32_t pxa = (k & 1) ? next_pair(xa[q + 1], xa[q]) : xa[q], pxb = (k & 1) ? next_pair(xb[q + 1], xb[q]) : xb[q];
-                                const uint32_t pya = (k & 1) ? next_pair(ya[q + 1], ya[q]) : ya[q], pyb = (k & 1) ? next_pair(yb[q + 1], yb[q]) : yb[q];
-                                sX[k] = dot2_acc(pxb, wbot, dot2_to_uniform(pxa, wtop, 1 << 13));   // 1 << 13: rounding term of the 14-bit descale
-                                sY[k] = dot2_acc(pyb, wbot, dot2_to_uniform(pya, wtop, 1 << 13));
-                            }
-                        }
-                        // pixel pairs for the template samples: region rows rc + 1, rc + 2, from image column ipx + x0 - 1
-                        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, ipx + x0 - 1 - RI.rx0, Rb);
-                        read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, ipx + x0 - 1 - RI.rx0, Rc);
-                    } else {
-                    // the lane interpolates between image rows ipy+rc and ipy+rc+1; their gradients need rows ipy+rc-1 .. +2,
-                    // which are region rows rc .. rc+3; columns ipx+x0-1 .. ipx+x0+SEGLEN+2
-                    const int boff = ipx + x0 - 1 - RI.rx0;
-                    uint32_t Ra[NP], Rd[NP];
-                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc, boff, Ra);
-                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 1, boff, Rb);
-                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 2, boff, Rc);
-                    const int gy = ipy + rc;
-                    // the two gradient rows one after the other (the scheduling fences keep their temporaries from overlapping)
-                    // (the column passes through an opaque assembly statement inside the border branch: otherwise the compiler
-                    // hoists the border masks' comparisons above the branch and every window pays for them)
-                    if (inside) scharr_row_blend<SEGLEN, false>(Ra, Rb, Rc, wtop, sX, sY, true, 0, w);
-                    else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Ra, Rb, Rc, wtop, sX, sY, gy >= 0 && gy < h, col0, w); }
-                    __builtin_amdgcn_sched_barrier(0);
-                    read_row_pairs_even<NP, LK_PITCH>(ilds, rc + 3, boff, Rd);
-                    if (inside) scharr_row_blend<SEGLEN, false>(Rb, Rc, Rd, wbot, sX, sY, true, 0, w);
-                    else { int col0 = ipx + x0 - 1; asm volatile("" : "+v"(col0)); scharr_row_blend<SEGLEN, true>(Rb, Rc, Rd, wbot, sX, sY, gy + 1 >= 0 && gy + 1 < h, col0, w); }
-                    __builtin_amdgcn_sched_barrier(0);
-                    }
-                    int a11 = 0, a12 = 0, a22 = 0;
-        #pragma unroll
-                    for (int m = 0; m < SEGLEN / 2; m++) {
-                        GX[m] = pack_lo16(sX[2 * m + 1] >> 14, sX[2 * m] >> 14) & keep[m];
-                        GY[m] = pack_lo16(sY[2 * m + 1] >> 14, sY[2 * m] >> 14) & keep[m];
-                        a11 = m == 0 ? dot2_to_zero(GX[m], GX[m]) : dot2_acc(GX[m], GX[m], a11);
-                        a12 = m == 0 ? dot2_to_zero(GX[m], GY[m]) : dot2_acc(GX[m], GY[m], a12);
-                        a22 = m == 0 ? dot2_to_zero(GY[m], GY[m]) : dot2_acc(GY[m], GY[m], a22);
-                    }
-        #pragma unroll
-                    for (int k = 0; k < SEGLEN; k++) {
-                        // sample k blends pixel columns c = k+1, k+2 of region rows rc+1, rc+2
-                        const uint32_t pb = (k & 1) ? Rb[(k + 1) / 2] : next_pair(Rb[k / 2 + 1], Rb[k / 2]);
-                        const uint32_t pc = (k & 1) ? Rc[(k + 1) / 2] : next_pair(Rc[k / 2 + 1], Rc[k / 2]);
-                        const int iw = dot2_acc(pc, wbot, dot2_to(pb, wtop, 256)) >> 9;
-                        Cw[k] = 256 - (iw << 9);
-                    }
-                    wave_sum_exact3(a11, a22, a12, A11, A22, A12);
-                    A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
-                }
-                const float D = A11 * A22 - A12 * A12;
-                // the smaller eigenvalue against the threshold: see lk_kernel
-                const float eig_tr = A22 + A11, eig_disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
-                bool eig_low;
-                {
-                    const float approx = (eig_tr - __builtin_amdgcn_sqrtf(eig_disc)) * inv_area;
-                    const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward;
-                    if (!want_value && fabsf(approx - min_eig_f) > (eig_tr * inv_area + min_eig_f) * 4e-6f) {
-                        eig_low = approx < min_eig_f;
-                    } else {
-                        const float minEig = (eig_tr - sqrtf(eig_disc)) / (float)(2 * ww * wh);
-                        eig_value = minEig;
-                        eig_low = (double)minEig < a.min_eig;
-                    }
-                }
-                code = (eig_low || D < 1.1920928955078125e-07f) ? 2 : 0;
+                lk_template<SEGLEN, TALL>(W, ilds, RI, G.px, G.py, G.ipx, G.ipy, w, h, Cw, GX, GY, A11, A12, A22);
+                code = lk_matrix_test<SEGLEN>(a, W, level, A11, A12, A22, eig_value);
 #pragma unroll
                 for (int k = 0; k < SEGLEN; k++) hand[k * 64 + lane] = (uint32_t)Cw[k];
 #pragma unroll
@@ -1012,10 +920,10 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
                 }
             }
             if (lane == 0) { hand_f[0] = A11; hand_f[1] = A12; hand_f[2] = A22; hand_f[3] = eig_value; hand_code = code; }
-        } else if (!tmpl_out) {
-            const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-            if (!(inx0 < -ww || inx0 >= w || iny0 < -wh || iny0 >= h)) {
-                R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx0 - LK_MARGIN, inx0 + ext_w + LK_MARGIN, iny0 - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
+        } else if (!G.tmpl_out) {
+            const int inx0 = lk_uniform_floor(G.nx), iny0 = lk_uniform_floor(G.ny);
+            if (!(inx0 < -W.ww || inx0 >= w || iny0 < -W.wh || iny0 >= h)) {
+                R = stage_region<J_ROWS, LK_PITCH>(jlds, G.imgJ, G.ipitch, w, h, inx0 - LK_MARGIN, inx0 + W.ext_w + LK_MARGIN, iny0 - LK_MARGIN, W.wh + 1 + 2 * LK_MARGIN, lane, W.reach_w, W.reach_h);
                 lds_fence();
             }
         }
@@ -1040,114 +948,19 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
 
         if (code == 1) {            // the template window lies outside the image
             if (level == 0) { st = 0; errv = 0.f; }
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
         } else {
             if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = eig_value;
             if (code == 2) {        // flat or degenerate template
                 if (level == 0) st = 0;
-                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             } else {
-                float D = A11 * A22 - A12 * A12;
-                D = 1.f / D;
-
-                // ---- Newton iterations on the target image, fed from LDS ----
-                float pdx = 0.f, pdy = 0.f;
-                n_iter = 0;
-                for (int j = 0; j < a.max_iter; j++) {
-                    const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
-                    if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
-                        if (level == 0) st = 0;
-                        break;
-                    }
-                    n_iter = j + 1;
-                    if (!region_holds(R, inx, iny, ext_w, wh)) {
-                        R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, inx - LK_MARGIN, inx + ext_w + LK_MARGIN, iny - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
-                        lds_fence();
-                    }
-                    const BilinW jw = bilin_weights(nx - inx, ny - iny);
-                    const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
-                    uint32_t p0[SEGLEN], p1[SEGLEN];
-                    const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
-                    read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
-                    read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
-                    int b1 = 0, b2 = 0;
-        #pragma unroll
-                    for (int m = 0; m < SEGLEN / 2; m++) {
-                        const int d0 = dot2_acc(p1[2 * m], wbot, dot2_to(p0[2 * m], wtop, Cw[2 * m])) >> 9;           // J - I, sample 2m
-                        const int d1 = dot2_acc(p1[2 * m + 1], wbot, dot2_to(p0[2 * m + 1], wtop, Cw[2 * m + 1])) >> 9;
-                        const uint32_t dp = pack_lo16(d1, d0);
-                        b1 = m == 0 ? dot2_to_zero(dp, GX[m]) : dot2_acc(dp, GX[m], b1);
-                        b2 = m == 0 ? dot2_to_zero(dp, GY[m]) : dot2_acc(dp, GY[m], b2);
-                    }
-                    float fb1, fb2;
-                    wave_sum_exact2(b1, b2, fb1, fb2);
-                    fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
-                    const float dx = (A12 * fb2 - A22 * fb1) * D;
-                    const float dy = (A12 * fb1 - A11 * fb2) * D;
-                    nx += dx; ny += dy;
-                    outx = nx + half_x; outy = ny + half_y;
-                    // delta . delta <= epsilon in double precision, as the reference computes it.  The float value decides
-                    // whenever it is clear of the bound by far more than its rounding error (a few 1e-7 relative); the double
-                    // arithmetic, at half the issue rate, runs only in the band around the bound.  Uniform for the wave.
-                    {
-                        const float s = dx * dx + dy * dy;
-                        const bool far = fabsf(s - eps_f) > eps_band;
-                        if (far ? s < eps_f : (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
-                    }
-                    // |dx + pdx| < 0.01 and |dy + pdy| < 0.01 in double precision: for a float, "< 0.01" is "< the float above 0.01"
-                    if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
-                        outx -= dx * 0.5f; outy -= dy * 0.5f;
-                        break;
-                    }
-                    pdx = dx; pdy = dy;
-                }
-                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
-
-                // ---- residual at the final position (level 0 only) ----
-                if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
-                    const float qx = outx - half_x, qy = outy - half_y;
-                    const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
-                    if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
-                        st = 0;
-                    } else if (!(a.flags & FT_LK_NO_ERROR)) {
-                        if (!region_holds(R, iqx, iqy, ext_w, wh)) {
-                            R = stage_region<J_ROWS, LK_PITCH>(jlds, imgJ, ipitch, w, h, iqx - LK_MARGIN, iqx + ext_w + LK_MARGIN, iqy - LK_MARGIN, wh + 1 + 2 * LK_MARGIN, lane, reach_w, reach_h);
-                            lds_fence();
-                        }
-                        const BilinW qw = bilin_weights(qx - iqx, qy - iqy);
-                        const uint32_t wtop = (uint32_t)qw.w00 | ((uint32_t)qw.w01 << 16), wbot = (uint32_t)qw.w10 | ((uint32_t)qw.w11 << 16);
-                        uint32_t p0[SEGLEN], p1[SEGLEN];
-                        const int boff = iqx - R.rx0 + x0, row = iqy - R.ry0 + rc;
-                        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
-                        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
-                        int e = 0;
-        #pragma unroll
-                        for (int k = 0; k < SEGLEN; k++) {
-                            const int diff = dot2_acc(p1[k], wbot, dot2_to(p0[k], wtop, Cw[k])) >> 9;
-                            if (k < n_valid) e += abs(diff);
-                        }
-                        const float errsum = (float)wave_sum_i32(e);   // < 2^24: exact
-                        errv = errsum * 1.f / (float)(32 * ww * wh);
-                    }
-                }
+                lk_track_level<SEGLEN, TALL>(a, W, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
                 __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
             }
         }
     }
-
-    if (!templater && lane == 0) {
-        if (!a.backward) {
-            a.next_xy[2 * pt] = outx;
-            a.next_xy[2 * pt + 1] = outy;
-            a.status[pt] = (uint8_t)st;
-            a.err[pt] = errv;
-        } else {
-            // forward-backward consistency: the backward track must succeed and return to the original point
-            const float dx = outx - gx0, dy = outy - gy0;
-            const float d2 = dx * dx + dy * dy;
-            if (!st || !(d2 <= a.fb_thresh2)) a.status[pt] = 0;
-        }
-    }
+    if (!templater && lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
 }
 
 // input block of a tracking batch: pinned host memory (read through its device address) -> device memory, 16 bytes
