@@ -59,7 +59,7 @@ MEASURED_TRAFFIC = {
 # pass over this workload (profiles/*_pmc_insts.txt).  These kernels are bound by vector-instruction issue, not by HBM:
 # one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
 MEASURED_VALU = {
-    ("cfg4", "lk_track"): (3440.5, "point"),                                   # one wave per point (profiles/r2_m_pmc_insts.txt)
+    ("cfg4", "lk_track"): (3476.8, "point"),                                   # one wave per point (profiles/r2_n_pmc_insts.txt)
     ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
     ("cfg4", "fast_grid"): ((863.5 * 13312 + 253.2 * 1600) / 64.0, "frame"),
     ("cfg4", "outlier_rejection"): (2929.5 * 256 / 8872.0, "point"),           # 256 waves per launch of 8872 points
