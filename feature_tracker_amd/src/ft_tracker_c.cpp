@@ -519,14 +519,16 @@ int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, 
     *out = nullptr;
     // groups overlap one group's host bookkeeping with the others' device work.  Measured on 64 streams: 3 groups
     // 63.5 M features/s, 2 groups 61.2 M, 4 groups 44.7 M (more submitting threads contend inside the HIP runtime, and
-    // batches below about 20 streams run the kernels less efficiently)
+    // batches below about 20 streams run the kernels less efficiently).  32 streams: 3 groups 48.2-49.0 M, 2 groups
+    // 47.0-47.6 M, 1 group 35 M; 16 streams: 2 groups 30.2 M, 3 groups 28.4-30.8 M, 1 group 24.5 M; 8 streams: 16-17 M
+    // whatever the number of groups (a step is then one chain of dependent launches and host work, about 70 us).
     // A fourth group pays (+ 2.5 %) when every group's queue gets a hardware queue of its own: a process has
     // GPU_MAX_HW_QUEUES of them (4 unless the environment says otherwise), shared by all its streams, and with four
     // hardware queues a fourth group shares one with another group and the rate collapses (37 M against 57 M).
     if (n_groups <= 0) {
         const char* hq = getenv("GPU_MAX_HW_QUEUES");
         const int hw_queues = hq ? atoi(hq) : 4;
-        n_groups = n_streams >= 48 ? ((hw_queues >= 8 && n_streams >= 64) ? 4 : 3) : (n_streams >= 8 ? 2 : 1);
+        n_groups = n_streams >= 32 ? ((hw_queues >= 8 && n_streams >= 64) ? 4 : 3) : (n_streams >= 8 ? 2 : 1);
     }
     n_groups = std::min(n_groups, n_streams);
     // host threads: one driver per group plus helpers for the per-stream bookkeeping inside each group

@@ -67,7 +67,7 @@ int ftk_tracker_database_size(ftk_tracker* t);
 int ftk_tracker_get_track(ftk_tracker* t, uint64_t id, int cam, float* uvn4, double* timestamps, int cap);
 
 /* ---- n independent monocular streams, batched ----
- * The streams are split into `n_groups` groups (0 = choose: 3 from 48 streams on, 2 from 8 on, else 1).  A group has its own device
+ * The streams are split into `n_groups` groups (0 = choose: 3 from 32 streams on, 2 from 8 on, else 1).  A group has its own device
  * context and queue, a host driver thread and a feature-database writer thread, so groups overlap each other's device
  * work and host bookkeeping.  host_threads (0 = choose: two per group) is the total number of host threads; threads
  * beyond two per group help with the per-stream bookkeeping inside the groups. */
