@@ -24,5 +24,12 @@ for r in range(3):
         marks.append(time.perf_counter() - t0)
     f.b.flush()
     t_end = time.perf_counter() - t0
+    spin = float(os.environ.get("PROBE_SPIN_US", "0")) * 1e-6   # busy-wait on the host before the synchronize
+    while time.perf_counter() - t0 - t_end < spin:
+        pass
     torch.cuda.synchronize()
+    t_sync = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_sync2 = time.perf_counter() - t0
+    print(f"region {r}: device synchronize after the flush returns at {1e6 * t_sync:.0f}, a second one at {1e6 * t_sync2:.0f}")
     print(f"region {r}: starts at {1e6 * t0:.0f} on the monotonic clock (FT_GROUP_TRACE=1 prints the groups' instants on it); feeds return at (us)", " ".join(f"{1e6 * m:.0f}" for m in marks), f"| flush done {1e6 * t_end:.0f}", flush=True)
