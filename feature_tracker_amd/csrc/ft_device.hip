@@ -71,6 +71,10 @@ struct ft_ctx {
     // tracking queue, a high-priority queue that waits for an event of a normal-priority queue can starve that queue
     // and hang the device.  With equal priorities the kernels only slow each other down (they are bound by vector
     // issue, not by latency) and the event traffic costs host time: 0.160 -> 0.178 ms per step with two stream groups.
+    // Small batches, whose kernels run at their latency floors, gain nothing either from 8 streams on (8 streams in
+    // one group 74.6 -> 74.2 us per step, 16 streams 92.8 -> 101 us; 4 streams 68.5 -> 58.3 us): a step is then the
+    // chain host preparation -> tracking -> outlier rejection -> host bookkeeping, and the next set's front work
+    // already runs on the device while the host does its part of that chain.
     hipStream_t q_ = nullptr;            // use enq(ctx) to put work on it
     // Completion flag of the outlier-rejection kernel: its last workgroup stores a sequence number to pinned host
     // memory, and a fence taken while that launch is the newest work on the queue is waited for by polling the flag
