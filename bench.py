@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 # HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
 # doubled as gfx950 requires; profiles/*_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
 MEASURED_TRAFFIC = {
-    ("cfg4", "lk_track"): (6588.8 + 17.7, "point"),                            # profiles/r2_m_pmc_hbm_traffic.json
+    ("cfg4", "lk_track"): (6588.8 + 17.7, "point"),                            # profiles/r2_n_pmc_hbm_traffic.json
     ("cfg4", "pyramid"): (491906.6 + 489636.8, "frame"),
     ("cfg4", "fast_grid"): (374039.9 + 16777.2 + 8272.0 + 3343.7, "frame"),    # detector + top-k
     ("cfg4", "outlier_rejection"): (104.3 + 13.7, "point"),
