@@ -798,7 +798,9 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     // Large batches: one transfer for the whole block (jobs .. end of next_xy in use), so that the tracking waves read
     // their inputs from device memory.  Small batches (a single stream's worth of points) read the pinned block in
-    // place: the extra dependent launch would cost more than the few reads over the bus.
+    // place: the extra dependent launch would cost more than the few reads over the bus.  (Not with the outlier
+    // rejection behind the tracking: its workgroups read the job records and points over the bus as well, and the
+    // single-stream latency went from 77 to 83 us, 8 streams from 16.9 to 16.3 M features/s.)
     const bool direct_in = N <= 1024 && !stereo && !reject;
     const uint8_t* ib = direct_in ? c->lk_in_host_dev : c->lk_in_dev;
     if (!direct_in) {
