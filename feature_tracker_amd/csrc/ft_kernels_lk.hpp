@@ -379,6 +379,29 @@ __device__ __forceinline__ void read_row_pairs(const uint32_t* __restrict__ lds,
     }
 }
 
+// The same in two steps: the row's bytes realigned to the window column (kept across Newton iterations that stay within
+// one pixel), and their unpacking into pairs.
+template <int SEGLEN, int LK_PITCH>
+__device__ __forceinline__ void read_row_aligned(const uint32_t* __restrict__ lds, int row, int byte_off, uint32_t (&e)[SEGLEN / 4 + 1]) {
+    constexpr int NDW = SEGLEN / 4 + 1;
+    const uint32_t* p = lds + row * LK_PITCH + (byte_off >> 2);
+    const uint32_t sh = byte_off & 3;
+    uint32_t d[NDW + 1];
+#pragma unroll
+    for (int q = 0; q <= NDW; q++) d[q] = p[q];
+#pragma unroll
+    for (int q = 0; q < NDW; q++) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+}
+template <int SEGLEN>
+__device__ __forceinline__ void unpack_row_pairs(const uint32_t (&e)[SEGLEN / 4 + 1], uint32_t (&pairs)[SEGLEN]) {
+#pragma unroll
+    for (int k = 0; k < SEGLEN; k++) {
+        const int q = k >> 2, b = k & 3;
+        if (b < 3) pairs[k] = __builtin_amdgcn_perm(0u, e[q], 0x0c000c00u | (uint32_t)b | ((uint32_t)(b + 1) << 16));
+        else pairs[k] = __builtin_amdgcn_perm(e[q + 1], e[q], 0x0c040c03u);
+    }
+}
+
 // One row of Scharr gradients on packed pairs, blended into the per-sample sums.  U, M, L: pixel pairs of the rows
 // above, at and below the gradient row; column index c of a pair array is image column ipx + x0 - 1 + c.
 // EDGE: zero the gradients that lie outside the image (the derivative image is zero-padded).
@@ -698,6 +721,8 @@ __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEG
     // ---- Newton iterations on the target image, fed from LDS ----
     float pdx = 0.f, pdy = 0.f;
     n_iter = 0;
+    uint32_t e0[SEGLEN / 4 + 1], e1[SEGLEN / 4 + 1];
+    int held_x = INT_MIN, held_y = INT_MIN;    // integer position whose rows e0, e1 hold
     for (int j = 0; j < a.max_iter; j++) {
         const int inx = lk_uniform_floor(nx), iny = lk_uniform_floor(ny);
         if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
@@ -711,10 +736,16 @@ __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEG
         }
         const BilinW jw = bilin_weights(nx - inx, ny - iny);
         const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
+        // most steps after the first stay within one pixel: the realigned rows are then those of the last iteration
+        if (inx != held_x || iny != held_y) {
+            const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
+            read_row_aligned<SEGLEN, LK_PITCH>(jlds, row, boff, e0);
+            read_row_aligned<SEGLEN, LK_PITCH>(jlds, row + 1, boff, e1);
+            held_x = inx; held_y = iny;
+        }
         uint32_t p0[SEGLEN], p1[SEGLEN];
-        const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
-        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row, boff, p0);
-        read_row_pairs<SEGLEN, LK_PITCH>(jlds, row + 1, boff, p1);
+        unpack_row_pairs<SEGLEN>(e0, p0);
+        unpack_row_pairs<SEGLEN>(e1, p1);
         int b1 = 0, b2 = 0;
 #pragma unroll
         for (int m = 0; m < SEGLEN / 2; m++) {
