@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 # HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
 # doubled as gfx950 requires; profiles/*_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
 MEASURED_TRAFFIC = {
-    ("cfg4", "lk_track"): (6588.8 + 17.7, "point"),                            # profiles/r2_n_pmc_hbm_traffic.json
+    ("cfg4", "lk_track"): (6590.5 + 17.6, "point"),                            # profiles/r2_o_pmc_hbm_traffic.json
     ("cfg4", "pyramid"): (491906.6 + 489636.8, "frame"),
     ("cfg4", "fast_grid"): (374039.9 + 16777.2 + 8272.0 + 3343.7, "frame"),    # detector + top-k
     ("cfg4", "outlier_rejection"): (104.3 + 13.7, "point"),
@@ -59,7 +59,7 @@ MEASURED_TRAFFIC = {
 # pass over this workload (profiles/*_pmc_insts.txt).  These kernels are bound by vector-instruction issue, not by HBM:
 # one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
 MEASURED_VALU = {
-    ("cfg4", "lk_track"): (3476.8, "point"),                                   # one wave per point (profiles/r2_n_pmc_insts.txt)
+    ("cfg4", "lk_track"): (3442.3, "point"),                                   # one wave per point (profiles/r2_o_pmc_insts.txt)
     ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
     ("cfg4", "fast_grid"): ((863.5 * 13312 + 253.2 * 1600) / 64.0, "frame"),
     ("cfg4", "outlier_rejection"): (2929.5 * 256 / 8872.0, "point"),           # 256 waves per launch of 8872 points
