@@ -9,10 +9,17 @@ handed over as host pointers (PCIe inside the clock) and the rate without the ou
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg5] [--scaling strong|weak]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run.  Nothing is exchanged in the data path.
---scaling strong (default; BASELINE configs[3]): the workload's streams are dealt to the ranks, stream s on rank
-s mod N.  --scaling weak: every rank runs the workload's full stream count.  Rank 0 prints one JSON line with the
-whole-job rate.
+N > 1: one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) the process is one of those ranks and
+refuses to run if WORLD_SIZE differs from --gpus; started plain, it launches the N ranks itself as a child
+torch.distributed.run (before anything touches the GPU), relays rank 0's JSON line and exits with the child's code.
+Nothing is exchanged in the data path.  --scaling strong (default; BASELINE configs[3]): the workload's streams are
+dealt to the ranks, stream s on rank s mod N.  --scaling weak: every rank runs the workload's full stream count.
+Rank 0 prints one JSON line with the whole-job rate.  --dry-run rehearses launch, sharding and the reduction of the
+totals without device work (value null), for boxes without N GPUs.
+
+The clock of a timed region starts after a barrier + device synchronize and stops when flush() returns, i.e. when
+every tracked position of the K steps is on the host and every observation is in the feature databases; the closing
+synchronize + barrier runs after that and is reported separately.
 """
 import argparse
 import ctypes
@@ -48,21 +55,23 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 # HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
 # doubled as gfx950 requires; profiles/*_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
+_T_SRC = "profiles/r2_o_pmc_hbm_traffic.json"
 MEASURED_TRAFFIC = {
-    ("cfg4", "lk_track"): (6590.5 + 17.6, "point"),                            # profiles/r2_o_pmc_hbm_traffic.json
-    ("cfg4", "pyramid"): (491906.6 + 489636.8, "frame"),
-    ("cfg4", "fast_grid"): (374039.9 + 16777.2 + 8272.0 + 3343.7, "frame"),    # detector + top-k
-    ("cfg4", "outlier_rejection"): (104.3 + 13.7, "point"),
+    ("cfg4", "lk_track"): (6590.5 + 17.6, "point", _T_SRC),
+    ("cfg4", "pyramid"): (491906.6 + 489636.8, "frame", _T_SRC),
+    ("cfg4", "fast_grid"): (374039.9 + 16777.2 + 8272.0 + 3343.7, "frame", _T_SRC),    # detector + top-k
+    ("cfg4", "outlier_rejection"): (104.3 + 13.7, "point", _T_SRC),
 }
 
 # Vector-ALU instructions per wavefront ("wave instructions") per unit of work, from a rocprofv3 SQ_INSTS_VALU / SQ_WAVES
 # pass over this workload (profiles/*_pmc_insts.txt).  These kernels are bound by vector-instruction issue, not by HBM:
 # one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
+_V_SRC = "profiles/r2_o_pmc_insts.txt"
 MEASURED_VALU = {
-    ("cfg4", "lk_track"): (3442.3, "point"),                                   # one wave per point (profiles/r2_o_pmc_insts.txt)
-    ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame"),
-    ("cfg4", "fast_grid"): ((863.5 * 13312 + 253.2 * 1600) / 64.0, "frame"),
-    ("cfg4", "outlier_rejection"): (2929.5 * 256 / 8872.0, "point"),           # 256 waves per launch of 8872 points
+    ("cfg4", "lk_track"): (3442.3, "point", _V_SRC),                                   # one wave per point
+    ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame", _V_SRC),
+    ("cfg4", "fast_grid"): ((863.5 * 13312 + 253.2 * 1600) / 64.0, "frame", _V_SRC),
+    ("cfg4", "outlier_rejection"): (2929.5 * 256 / 8872.0, "point", _V_SRC),           # 256 waves per launch of 8872 points
 }
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0
 
@@ -189,111 +198,112 @@ class Feeder:
         return tracked + tr, attempted + at
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=100, help="untimed steps before the timed regions (the pipeline needs about 100 steps = 15 ms to reach its steady rate: measured 58-63 M features/s in a first region after 8 or 30 steps, 66 M after 100)")
-    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="N > 1: strong = the workload's streams dealt to the ranks (s mod N); weak = the full stream count on every rank")
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; the first is `value`, all are reported")
-    ap.add_argument("--groups", type=int, default=0, help="stream groups per GPU (0 = library default)")
-    ap.add_argument("--host-threads", type=int, default=0, help="host threads per GPU (0 = library default)")
-    ap.add_argument("--host-frames", action="store_true", help="headline leg fed from host memory (for profiling that leg alone)")
-    ap.add_argument("--no-reject-outliers", action="store_true", help="headline leg without the outlier rejection (for profiling)")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-frame / no-rejection / gradient-image legs")
-    ap.add_argument("--streams", type=int, default=0, help="override the workload's stream count (experiments; the JSON line says so)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency", action="store_true")
-    args = ap.parse_args()
+def launch_ranks(n, argv):
+    """Plain `bench.py --gpus N`: start the N ranks as a child torch.distributed.run, relay rank 0's JSON line and the
+    child's exit code.  Runs before this process has imported torch or touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
 
-    import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
-    # one rank per GPU; FT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path on a
-    # one-GPU box (RCCL refuses two ranks on one device)
-    backend = os.environ.get("FT_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+def kernel_report(name, wl, S, kt, ev_overhead_ms, step_ms, host_frames, pmc_ok):
+    """Per-kernel-group figures of one workload from the HIP-event times in `kt` (one launch group = one step of all S
+    streams of this GPU) and the group with the most device time per step."""
+    w, h, lv, win = wl["w"], wl["h"], wl["opts"]["pyr_levels"], wl["opts"]["win_size"]
+    fb = 2 if wl["opts"].get("forward_backward") else 1
+    pyr_bytes = pyramid_kernel_bytes(w, h, lv, with_gradients=False, with_ingest=not host_frames) * S
+    lk_bytes = lk_kernel_bytes(win, kt.lk_level_visits, kt.lk_iterations) / max(1, kt.lk_launches)
+    kinds = {
+        "pyramid": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
+        "lk_track": (kt.lk_ms, kt.lk_launches, lk_bytes),
+        "fast_grid": (kt.fast_ms, kt.fast_launches, w * h * S),
+        # per point: both positions and the status in, the normalized pair out and in again, the results out
+        "outlier_rejection": (kt.reject_ms, kt.reject_launches, 66 * kt.lk_points / max(1, kt.lk_launches)),
+    }
+    per_kernel = {}
+    for kname, (ms, n, by) in kinds.items():
+        if n:
+            avg = max(ms / n - ev_overhead_ms, 1e-6)
+            e = dict(avg_ms=avg, launches=n, share_of_step=avg / step_ms)
+            if by:
+                e.update(algorithmic_bytes=by, achieved_gbs=by / (avg * 1e-3) / 1e9, frac_hbm_peak=by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            per_kernel[kname] = e
+    if kt.lk_launches:
+        per_kernel["lk_track"].update(points_per_launch=kt.lk_points / kt.lk_launches,
+                                      level_visits_per_point=kt.lk_level_visits / max(1, kt.lk_points),
+                                      iterations_per_level_visit=kt.lk_iterations / max(1, kt.lk_level_visits),
+                                      kernels_per_group=fb, note="forward + backward pass per launch group" if fb == 2 else None)
+    units = {"point": kt.lk_points / max(1, kt.lk_launches), "frame": float(S)}
+    for kname, e in per_kernel.items():
+        # not measured in this run: per-unit figures of the named rocprofv3 counter pass times this run's unit counts
+        m = MEASURED_TRAFFIC.get((name, kname)) if pmc_ok else None
+        e["hbm_traffic_bytes"] = m[0] * units[m[1]] if m else None
+        e["hbm_traffic_source"] = (m[2] + " (per " + m[1] + ", times this run's count)") if m else None
+        v = MEASURED_VALU.get((name, kname)) if pmc_ok else None
+        if v:
+            e["valu_wave_insts"] = v[0] * units[v[1]]
+            e["valu_issue_frac"] = e["valu_wave_insts"] / (e["avg_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S
+            e["valu_source"] = v[2] + " (per " + v[1] + ", times this run's count)"
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
+    return per_kernel, dom
 
-    from feature_tracker_amd import device as ftdev
-    from feature_tracker_amd import tracker
-    from feature_tracker_amd.sharding import reduce_run_totals
 
-    wl = dict(WORKLOADS[args.workload])
-    if args.streams > 0:
-        wl["streams"] = args.streams
-        wl["desc"] = wl["desc"] + f" [stream count overridden: {args.streams}]"
-    K, W, R = args.steps, args.warmup, max(1, args.repeats)
-    n_frames = W + 1 + R * K                   # the first frame only detects
-    threads = min(16, os.cpu_count() or 8)
-    ids = stream_ids_of_rank(wl, args.scaling, rank, world)
-    S = len(ids)
-    w, h = wl["w"], wl["h"]
-    t_gen = time.perf_counter()
-    seqs = make_sequences(wl, n_frames, ids, threads)
-    t_gen = time.perf_counter() - t_gen
+KERNEL_NAMES = {"pyramid": "level_kernel (frame ingest + pyrDown, one launch per level, all streams of one step)",
+                "lk_track": "lk_kernel (template + Newton iterations, all levels, all features of one step)",
+                "fast_grid": "fast_detect_kernel + fast_topk_kernel (all streams of one step)",
+                "outlier_rejection": "ransac_kernel (undistortion, hypotheses, inlier counts, final mask)"}
 
-    # frames resident in HBM before anything is timed
-    dev_frames = [torch.from_numpy(q.frames).to(dev) for q in seqs]
-    torch.cuda.synchronize()
 
-    def barrier():
+class Bench:
+    """Everything one rank needs to measure workloads: the device, the libraries and the rank layout."""
+
+    def __init__(self, args, rank, world, local_rank, backend, dev, dist):
+        from feature_tracker_amd import device as ftdev
+        from feature_tracker_amd import tracker
+        from feature_tracker_amd.sharding import reduce_run_totals
+        self.args, self.rank, self.world, self.local_rank, self.backend, self.dev, self.dist = args, rank, world, local_rank, backend, dev, dist
+        self.ftdev, self.tracker, self._reduce = ftdev, tracker, reduce_run_totals
+        self.lib = ftdev.load_library()
+        self.threads = min(16, os.cpu_count() or 8)
+
+    def reduce(self, dt, counts):
+        return self._reduce(dt, counts, device=self.dev if self.backend == "nccl" else None)
+
+    def barrier(self):
+        import torch
         torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
+        if self.world > 1:
+            self.dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_leg(host_frames, **more_opts):
-        """W warm-up steps (plus the detecting first frame), then R timed regions of exactly K steps each, every
-        region bracketed by barrier + synchronize.  Returns the per-region (dt_max, tracked_all, attempted_all)."""
-        f = Feeder(tracker, wl, seqs, dev_frames, local_rank, args.groups, args.host_threads, host_frames, **more_opts) if S else None
-        if f:
-            f.run(0, W + 1)
-        regions = []
-        stages = None
-        for r in range(R):
-            barrier()
-            if f:
-                f.b.stage_times(reset=True)
-            t0 = time.perf_counter()
-            tr, at = f.run(W + 1 + r * K, K) if f else (0, 0)
-            barrier()
-            dt = time.perf_counter() - t0
-            if f and r == 0:
-                stages = f.b.stage_times()
-            dt_max, (tr_all, at_all) = reduce_run_totals(dt, [tr, at], device=dev if backend == "nccl" else None)
-            regions.append((dt_max, tr_all, at_all))
-        groups = f.b.groups() if f else 0
-        del f
-        return regions, stages, groups
+    def load(self, wl, n_frames):
+        """Sequences of this rank's streams, generated on the host and made resident in HBM before anything is timed."""
+        import torch
+        ids = stream_ids_of_rank(wl, self.args.scaling, self.rank, self.world)
+        t = time.perf_counter()
+        seqs = make_sequences(wl, n_frames, ids, self.threads)
+        t = time.perf_counter() - t
+        dev_frames = [torch.from_numpy(q.frames).to(self.dev) for q in seqs]
+        torch.cuda.synchronize()
+        return seqs, dev_frames, t
 
-    head_opts = dict(reject_outliers=0) if args.no_reject_outliers else {}
-
-    # ---- per-kernel device time over the K steps of the timed region (HIP events on the tracker's own queue) ----
-    # Runs before the timed legs: the device and the host allocator are then in their steady state when the clock starts.
-    # One stream group (one device context, one queue), synchronous feeds, so that a kernel's events bracket that
-    # kernel alone.  The kernels launched are those of the timed leg (ft_profile mode 1 changes nothing but the
-    # events); the work counters of the tracking kernel come from a second, untimed pass (mode 2) over the same frames.
-    kt = ftdev.ft_kernel_time()
-    ev_overhead_ms = 0.0
-    if S:   # every rank runs it (only rank 0 reports it): all GPUs start the timed legs in the same state
-        lib = ftdev.load_library()
-        f2 = Feeder(tracker, wl, seqs, dev_frames, local_rank, 1, args.host_threads, args.host_frames, **head_opts)
+    def kernel_times(self, wl, seqs, dev_frames, K, W, host_frames, **opts):
+        """Per-kernel device time over K steps (HIP events on the tracker's own queue).  One stream group (one device
+        context, one queue), synchronous feeds, so that a kernel's events bracket that kernel alone.  The kernels
+        launched are those of the timed leg (ft_profile mode 1 changes nothing but the events); the work counters of
+        the tracking kernel come from a second, untimed pass (mode 2) over the same frames."""
+        lib, ftdev = self.lib, self.ftdev
+        kt = ftdev.ft_kernel_time()
+        f2 = Feeder(self.tracker, wl, seqs, dev_frames, self.local_rank, 1, self.args.host_threads, host_frames, **opts)
         ctx2 = ctypes.c_void_p(f2.b.group_ctx(0))
         for i in range(W + 1):
             f2.feed(i, pipelined=False)
@@ -311,7 +321,7 @@ def main():
             ov.append(ms.value)
         ev_overhead_ms = float(np.median(ov))
         del f2
-        f3 = Feeder(tracker, wl, seqs, dev_frames, local_rank, 1, args.host_threads, args.host_frames, **head_opts)
+        f3 = Feeder(self.tracker, wl, seqs, dev_frames, self.local_rank, 1, self.args.host_threads, host_frames, **opts)
         ctx3 = ctypes.c_void_p(f3.b.group_ctx(0))
         for i in range(W + 1):
             f3.feed(i, pipelined=False)
@@ -323,78 +333,192 @@ def main():
         lib.ft_profile(ctx3, 0)
         del f3
         kt.lk_points, kt.lk_level_visits, kt.lk_iterations = kc.lk_points, kc.lk_level_visits, kc.lk_iterations
+        return kt, ev_overhead_ms
 
-    regions, host_stages, groups = timed_leg(args.host_frames, **head_opts)
-    dt_max, tracked_all, attempted_all = regions[0]
-    streams_total = S if not distributed else int(reduce_run_totals(0.0, [S], device=dev if backend == "nccl" else None)[1][0])
+    def timed_leg(self, wl, seqs, dev_frames, K, W, R, host_frames, **opts):
+        """W warm-up steps (plus the detecting first frame), then R timed regions of exactly K steps each.  A region
+        starts after barrier + synchronize; its clock stops when flush() returns (every result of the K steps is on
+        the host and in the feature databases); the closing synchronize + barrier follows and is timed separately.
+        Returns per region (dt_max, tracked_all, attempted_all, dt_closed_max)."""
+        S = len(seqs)
+        f = Feeder(self.tracker, wl, seqs, dev_frames, self.local_rank, self.args.groups, self.args.host_threads, host_frames, **opts) if S else None
+        if f:
+            f.run(0, W + 1)
+        regions = []
+        stages = None
+        for r in range(R):
+            self.barrier()
+            if f:
+                f.b.stage_times(reset=True)
+            t0 = time.perf_counter()
+            tr, at = f.run(W + 1 + r * K, K) if f else (0, 0)
+            dt = time.perf_counter() - t0
+            self.barrier()
+            dt_closed = time.perf_counter() - t0
+            if f and r == 0:
+                stages = f.b.stage_times()
+            dt_max, (tr_all, at_all) = self.reduce(dt, [tr, at])
+            dt_closed_max, _ = self.reduce(dt_closed, [0])
+            regions.append((dt_max, tr_all, at_all, dt_closed_max))
+        groups = f.b.groups() if f else 0
+        del f
+        return regions, stages, groups
 
+    def side_workload(self, name, wl, K, W, seqs=None, dev_frames=None, cpu_budget_s=0.0):
+        """A further configuration of the same run, single GPU: one timed region of K steps after W warm-up steps, and the
+        per-kernel device times of the same K steps."""
+        t_gen = 0.0
+        if seqs is None:
+            seqs, dev_frames, t_gen = self.load(wl, W + 1 + K)
+        S = len(seqs)
+        kt, ov = self.kernel_times(wl, seqs, dev_frames, K, W, False)
+        regions, stages, groups = self.timed_leg(wl, seqs, dev_frames, K, W, 1, False)
+        dt, tr, at, dt_closed = regions[0]
+        per_kernel, dom = kernel_report(name, wl, S, kt, ov, 1e3 * dt / K, False, True)
+        out = dict(workload=wl["desc"], value=tr / dt, unit="features/s", steps=K, warmup=W, streams=S,
+                   ms_per_step=1e3 * dt / K, ms_per_frame=1e3 * dt / (K * S), ms_per_step_incl_closing_sync=1e3 * dt_closed / K,
+                   points_per_step=at / K, tracked_fraction=tr / max(1.0, at), kernels=per_kernel,
+                   dominant_kernel=KERNEL_NAMES.get(dom), host_stage_ms=stages, stream_groups=groups,
+                   sequence_generation_s=t_gen)
+        if cpu_budget_s > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, self.threads, budget_s=cpu_budget_s)
+        return out
+
+
+def dry_run(args, rank, world):
+    """Launch, sharding and reduction rehearsal without device work."""
+    import torch.distributed as dist
+    from feature_tracker_amd.sharding import reduce_run_totals
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    wl = dict(WORKLOADS[args.workload])
+    if args.streams > 0:
+        wl["streams"] = args.streams
+    ids = stream_ids_of_rank(wl, args.scaling, rank, world)
+    _, (total,) = reduce_run_totals(0.0, [len(ids)])
+    if rank == 0:
+        print(json.dumps({"metric": "tracked_features_per_sec", "value": None, "unit": "features/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True,
+                          "scaling": "weak" if (args.scaling == "weak" or wl.get("per_gpu")) else "strong",
+                          "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_total": int(total), "streams_this_gpu": len(ids)},
+                          "process_group": {"backend": "gloo" if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100, help="untimed steps before the timed regions (the pipeline needs about 100 steps = 15 ms to reach its steady rate: measured 58-63 M features/s in a first region after 8 or 30 steps, 66 M after 100)")
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's streams dealt to the ranks (s mod N); weak = the full stream count on every rank")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each; the first is `value`, all are reported")
+    ap.add_argument("--groups", type=int, default=0, help="stream groups per GPU (0 = library default)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads per GPU (0 = library default)")
+    ap.add_argument("--host-frames", action="store_true", help="headline leg fed from host memory (for profiling that leg alone)")
+    ap.add_argument("--no-reject-outliers", action="store_true", help="headline leg without the outlier rejection (for profiling)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-frame / no-rejection / gradient-image legs and the other workloads")
+    ap.add_argument("--streams", type=int, default=0, help="override the workload's stream count (experiments; the JSON line says so)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse launch, sharding and reduction without device work (value null)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    # ---- the rank layout, before anything touches the GPU ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run plain and let --gpus start them)", file=sys.stderr)
+        sys.exit(2)
+    distributed = world > 1
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    # one rank per GPU; FT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path on a
+    # one-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("FT_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        print(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) (FT_BENCH_BACKEND=gloo rehearses on fewer)", file=sys.stderr)
+        sys.exit(2)
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B = Bench(args, rank, world, local_rank, backend, dev, dist)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.streams > 0:
+        wl["streams"] = args.streams
+        wl["desc"] = wl["desc"] + f" [stream count overridden: {args.streams}]"
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
+    n_frames = W + 1 + R * K                   # the first frame only detects
+    seqs, dev_frames, t_gen = B.load(wl, n_frames)
+    S = len(seqs)
+    w, h = wl["w"], wl["h"]
+
+    head_opts = dict(reject_outliers=0) if args.no_reject_outliers else {}
+
+    # Per-kernel device times first: the device and the host allocator are then in their steady state when the clock
+    # starts.  Every rank runs it (only rank 0 reports it): all GPUs start the timed legs in the same state.
+    kt, ev_overhead_ms = (B.kernel_times(wl, seqs, dev_frames, K, W, args.host_frames, **head_opts) if S
+                          else (B.ftdev.ft_kernel_time(), 0.0))
+
+    regions, host_stages, groups = B.timed_leg(wl, seqs, dev_frames, K, W, R, args.host_frames, **head_opts)
+    dt_max, tracked_all, attempted_all, dt_closed_max = regions[0]
+    streams_total = S if not distributed else int(B.reduce(0.0, [S])[1][0])
+
+    single = world == 1 and not args.no_extra_legs and not args.host_frames and not args.no_reject_outliers
     extra = {}
-    if world == 1 and not args.no_extra_legs and not args.host_frames and not args.no_reject_outliers:
+    if single:
         # the same K steps with the frames handed over as host pointers (copied into pinned staging by the library's
         # threads, level 0 built by a pass that reads the staging over the bus): PCIe inside the clock
-        rg, _, _ = timed_leg(True)
-        vals = [tr / dt for dt, tr, _ in rg]
+        rg, _, _ = B.timed_leg(wl, seqs, dev_frames, K, W, R, True)
+        vals = [r[1] / r[0] for r in rg]
         extra["value_host_frames"] = vals[0]
         extra["host_frames"] = dict(ms_per_step=1e3 * rg[0][0] / K, repeats=vals, pcie_gbs=S * w * h * K / rg[0][0] / 1e9,
                                     note="frames passed as host pointers every step; PCIe-inclusive")
-        # ... and without the outlier rejection (mask = LK status), the configuration of the previous round's headline
-        rg, _, _ = timed_leg(False, reject_outliers=0)
-        vals = [tr / dt for dt, tr, _ in rg]
+        # ... and without the outlier rejection (mask = LK status)
+        rg, _, _ = B.timed_leg(wl, seqs, dev_frames, K, W, R, False, reject_outliers=0)
+        vals = [r[1] / r[0] for r in rg]
         extra["value_without_outlier_rejection"] = vals[0]
         extra["without_outlier_rejection"] = dict(ms_per_step=1e3 * rg[0][0] / K, repeats=vals)
 
     if rank == 0:
         lv, win = wl["opts"]["pyr_levels"], wl["opts"]["win_size"]
-        fb = 2 if wl["opts"].get("forward_backward") else 1
-        # algorithmic bytes per launch group (= one step of all streams of this GPU)
-        pyr_bytes = pyramid_kernel_bytes(w, h, lv, with_gradients=False, with_ingest=not args.host_frames) * S
-        lk_bytes = lk_kernel_bytes(win, kt.lk_level_visits, kt.lk_iterations) / max(1, kt.lk_launches)
-        kinds = {
-            "pyramid": (kt.pyramid_ms, kt.pyramid_launches, pyr_bytes),
-            "lk_track": (kt.lk_ms, kt.lk_launches, lk_bytes),
-            "fast_grid": (kt.fast_ms, kt.fast_launches, w * h * S),
-            # per point: both positions and the status in, the normalized pair out and in again, the results out
-            "outlier_rejection": (kt.reject_ms, kt.reject_launches, 66 * kt.lk_points / max(1, kt.lk_launches)),
-        }
-        kernel_names = {"pyramid": "level_kernel (frame ingest + pyrDown, one launch per level, all streams of one step)",
-                        "lk_track": "lk_kernel (template + Newton iterations, all levels, all features of one step)",
-                        "fast_grid": "fast_detect_kernel + fast_topk_kernel (all streams of one step)",
-                        "outlier_rejection": "ransac_kernel (undistortion, hypotheses, inlier counts, final mask; one workgroup per stream)"}
-        per_kernel = {}
-        for name, (ms, n, by) in kinds.items():
-            if n:
-                avg = max(ms / n - ev_overhead_ms, 1e-6)
-                e = dict(avg_ms=avg, launches=n, share_of_step=avg / (1e3 * dt_max / K))
-                if by:
-                    e.update(algorithmic_bytes=by, achieved_gbs=by / (avg * 1e-3) / 1e9, frac_hbm_peak=by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                per_kernel[name] = e
-        if kt.lk_launches:
-            per_kernel["lk_track"].update(points_per_launch=kt.lk_points / kt.lk_launches,
-                                          level_visits_per_point=kt.lk_level_visits / max(1, kt.lk_points),
-                                          iterations_per_level_visit=kt.lk_iterations / max(1, kt.lk_level_visits),
-                                          kernels_per_group=fb, note="forward + backward pass per launch group" if fb == 2 else None)
-        # the roofline entry describes the kernel group that takes the most device time per step
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
-        pk = per_kernel.get(dom, {})
-        units = {"point": kt.lk_points / max(1, kt.lk_launches), "frame": float(S)}
         plain = not (args.host_frames or args.no_reject_outliers) and world == 1
-        for name, e in per_kernel.items():
-            m = MEASURED_TRAFFIC.get((args.workload, name)) if plain else None
-            e["hbm_traffic_bytes"] = m[0] * units[m[1]] if m else None
-            v = MEASURED_VALU.get((args.workload, name)) if plain else None
-            if v:
-                e["valu_wave_insts"] = v[0] * units[v[1]]
-                e["valu_issue_frac"] = e["valu_wave_insts"] / (e["avg_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S
-        roofline = dict(kernel=kernel_names.get(dom), bound="hbm", achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS,
+        per_kernel, dom = kernel_report(args.workload, wl, S, kt, ev_overhead_ms, 1e3 * dt_max / K, args.host_frames, plain)
+        pk = per_kernel.get(dom, {})
+        roofline = dict(kernel=KERNEL_NAMES.get(dom), bound="hbm", achieved=pk.get("achieved_gbs"), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=pk.get("frac_hbm_peak"), traffic=pk.get("hbm_traffic_bytes"),
+                        traffic_source=pk.get("hbm_traffic_source"),
                         avg_launch_ms=pk.get("avg_ms"), algorithmic_bytes_per_launch=pk.get("algorithmic_bytes"),
                         event_pair_overhead_ms=ev_overhead_ms,
                         measured="HIP events on the context's queue, one stream group, the timed leg's kernels; the time of an "
                                  "empty event pair is subtracted",
                         # what actually limits this kernel: vector-instruction issue (measured instruction count
                         # over the issue capacity of the device during the launch)
-                        limiter="vector issue", valu_issue_frac=pk.get("valu_issue_frac"))
-        vals = [tr / dt for dt, tr, _ in regions]
+                        limiter="vector issue", valu_issue_frac=pk.get("valu_issue_frac"), valu_source=pk.get("valu_source"))
+        vals = [r[1] / r[0] for r in regions]
         out = {
             "metric": "tracked_features_per_sec", "value": tracked_all / dt_max, "unit": "features/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True,
@@ -405,6 +529,10 @@ def main():
                        "frames_in_hbm": not args.host_frames, "outlier_rejection": not args.no_reject_outliers,
                        "forward_backward": bool(wl["opts"].get("forward_backward")), "drop_fraction": wl["opts"].get("drop_fraction", 0.0),
                        "scene": wl.get("seq", {}).get("scene", "shapes")},
+            "clock": "barrier + synchronize, first feed ... flush() returned (all results of the K steps on the host, databases "
+                     "written), slowest rank; the closing synchronize + barrier comes after it",
+            "ms_per_step_incl_closing_sync": 1e3 * dt_closed_max / K,
+            "process_group": {"backend": backend if distributed else None, "world_size": dist.get_world_size() if distributed else 1},
             "repeats": {"values": vals, "min": min(vals), "median": float(np.median(vals)), "max": max(vals),
                         "note": f"{R} consecutive timed regions of {K} steps; `value` is the first"},
             "tracked_fraction": tracked_all / max(1.0, attempted_all),
@@ -417,12 +545,24 @@ def main():
             "setup": {"sequence_generation_s": t_gen},
         }
         out.update(extra)
-        if world == 1 and not args.no_extra_legs and not args.host_frames:
-            out["kernels"]["pyramid_gradient_build"] = pyramid_gradient_build(ftdev, wl, seqs, local_rank)
+        if single:
+            out["kernels"]["pyramid_gradient_build"] = pyramid_gradient_build(B.ftdev, wl, seqs, local_rank)
+        if single and args.workload == "cfg4" and args.streams == 0:
+            # the other configurations, short legs of the same run: the reference's own 15x15 window on the same
+            # streams, the 1280x720 forward-backward configuration and the 3840x2160 one
+            K2, W2 = min(K, 20), min(W, 10)
+            sides = {}
+            wl15 = dict(wl, desc=wl["desc"].replace("win 21", "win 15 (the reference's window, src/track/TrackKLT.h:122)"),
+                        opts=dict(wl["opts"], win_size=15))
+            sides["cfg4_win15"] = B.side_workload("cfg4_win15", wl15, K2, W2, seqs, dev_frames,
+                                                  cpu_budget_s=0.0 if args.no_cpu_baseline else 6.0)
+            for name in ("cfg3", "cfg5"):
+                sides[name] = B.side_workload(name, WORKLOADS[name], K2, W2)
+            out["workloads"] = sides
         if not args.no_latency and world == 1:
-            out["latency"] = single_stream_latency(tracker, local_rank)
+            out["latency"] = single_stream_latency(B.tracker, local_rank)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on a single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(wl, threads)
+            out["cpu_baseline"] = cpu_baseline(wl, B.threads)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

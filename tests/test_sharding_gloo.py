@@ -87,20 +87,50 @@ def test_bench_stream_assignment_for_both_scaling_modes():
     assert per_gpu.get("per_gpu") and all(len(bench.stream_ids_of_rank(per_gpu, "strong", r, 8)) == per_gpu["streams"] for r in range(8))
 
 
+def _bench_line(argv, env=None, timeout=300):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """Plain `bench.py --gpus 2` (no launcher around it) starts two ranks as a child torch.distributed.run and relays
+    rank 0's line; --dry-run rehearses launch, sharding and the reduction without device work."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res, out = _bench_line(["--gpus", "2", "--dry-run"], env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["dry_run"] and out["value"] is None
+    assert out["config"]["streams_total"] == 64 and out["config"]["streams_this_gpu"] == 32
+    assert out["process_group"] == {"backend": "gloo", "world_size": 2}
+    res, out = _bench_line(["--gpus", "4", "--dry-run", "--workload", "cfg5"], env=env)   # per-GPU workload: weak by definition
+    assert res.returncode == 0 and out["n_gpus"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["streams_total"] == 4 and out["config"]["streams_this_gpu"] == 1
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """Under a launcher WORLD_SIZE must equal --gpus: a mismatch (the flag ignored, or a wrong launch) exits non-zero
+    before any work."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    res, out = _bench_line(["--gpus", "2", "--dry-run"], env=env)
+    assert res.returncode == 2 and out is None and "WORLD_SIZE=3" in res.stderr
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res, out = _bench_line(["--dry-run"], env=env)     # --gpus defaults to 1
+    assert res.returncode == 2 and out is None
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_two_ranks_on_one_gpu(scaling, tmp_path):
-    """bench.py itself with two ranks (gloo for the reduction of the totals, both ranks on GPU 0): the JSON line names the
-    scaling mode and the total stream count, and the job's rate is the sum over ranks divided by the slowest rank's time."""
-    env = dict(os.environ, FT_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "1",
-           "--workload", "cfg2" if scaling == "weak" else "cfg4", "--scaling", scaling]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    """bench.py --gpus 2, started plain: it launches its two ranks itself (gloo for the reduction of the totals, both ranks
+    on GPU 0).  The JSON line names the scaling mode and the total stream count, and the job's rate is the sum over
+    ranks divided by the slowest rank's time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FT_BENCH_BACKEND"] = "gloo"
+    res, out = _bench_line(["--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "1",
+                            "--workload", "cfg2" if scaling == "weak" else "cfg4", "--scaling", scaling], env=env)
     assert res.returncode == 0, res.stderr[-3000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 6 and out["warmup"] == 2
+    assert out["process_group"] == {"backend": "gloo", "world_size": 2}
     want_total = 64 if scaling == "strong" else 2
     assert out["config"]["streams_total"] == want_total and out["config"]["streams_this_gpu"] == want_total // 2
     assert out["value"] > 0 and abs(out["frames_per_sec"] - want_total * 6 / (out["ms_per_step"] * 6e-3)) < 1e-6 * out["frames_per_sec"]
