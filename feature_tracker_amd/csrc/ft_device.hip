@@ -31,6 +31,8 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int FT_RO_ERROR_WORD = 16;   // word of the pinned completion-flag block that the rejection kernel sets when a barrier gave up
+
 struct SlotState {
     int w = 0, h = 0;
     int levels = 0;        // images valid (0 = no frame)
@@ -82,6 +84,9 @@ struct ft_ctx {
     unsigned* done_count_dev = nullptr;  // device: workgroups of the launch that have finished
     unsigned* done_flag_host = nullptr;  // pinned
     unsigned* done_flag_dev = nullptr;   // its device address
+    int* ro_gcnt_dev = nullptr;          // outlier rejection, pairs split over workgroups: inlier totals [pair][RO_MAX_HYP]
+    unsigned* ro_gbar_dev = nullptr;     // ... and per pair {barrier arrivals, finished parts}; both zero between launches
+    bool ro_split = true;                // FT_RO_SPLIT=0: one workgroup per pair whatever its size
     uint32_t done_seq = 0;               // last sequence number handed to a launch
     uint32_t tail_flag_seq = 0;          // != 0: the newest work on the queue is the launch that stores this number
     ArenaDesc arena{};
@@ -233,6 +238,18 @@ int deliver_pending(ft_ctx* c, uint64_t upto) {
     }
     if (c->lk_pending.active && c->lk_pending.seq <= upto) {
         PendingLK& P = c->lk_pending;
+        if (c->done_flag_host[FT_RO_ERROR_WORD]) {
+            // a part of a split pair gave up waiting for the others: the batch's masks are void.  The kernel leaves
+            // its counters clean when all parts finish; they are cleared here all the same.
+            c->done_flag_host[FT_RO_ERROR_WORD] = 0;
+            (void)hipStreamSynchronize(c->q_);
+            (void)hipMemset(c->ro_gcnt_dev, 0, sizeof(int) * FT_MAX_BATCH * RO_MAX_HYP);
+            (void)hipMemset(c->ro_gbar_dev, 0, sizeof(unsigned) * 2 * FT_MAX_BATCH);
+            P.active = false;
+            std::lock_guard<std::mutex> lk(c->err_mutex);
+            c->hip_err = "ransac_kernel: the workgroups of a split pair did not meet at their barrier";
+            return FT_E_HIP;
+        }
         const size_t N = (size_t)P.total;
         const float* xy = reinterpret_cast<const float*>(c->lk_out_host);
         const float* er = reinterpret_cast<const float*>(c->lk_out_host + 8 * N);
@@ -267,14 +284,29 @@ int sync_and_deliver(ft_ctx* c) {
     return deliver_pending(c, ~0ull);
 }
 
-// max_points: the largest job of the launch
-void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, int max_points) {
+// counts[j]: points of pair j.  Pairs of more than RO_CHUNK points are split into parts, one workgroup each, as long as
+// the launch then has at most RO_MAX_WGS workgroups: the parts of a pair wait for each other inside the kernel, so all
+// of them must be resident at once (256 threads and the hypothesis phase's registers: two workgroups per compute unit).
+void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, const int* counts) {
     EventPair ep;
     prof_begin(c, 3, ep);
     const uint32_t seq = ++c->done_seq ? c->done_seq : ++c->done_seq;   // never 0
     o.done_count = c->done_count_dev; o.done_flag = c->done_flag_dev; o.done_seq = seq;
-    if (max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(n_jobs), dim3(512), 0, enq(c), o);   // 512: the most that leaves the hypothesis phase its 193 registers
-    else hipLaunchKernelGGL(ransac_kernel<256>, dim3(n_jobs), dim3(256), 0, enq(c), o);
+    o.gcnt = c->ro_gcnt_dev; o.gbar = c->ro_gbar_dev; o.error_flag = c->done_flag_dev + FT_RO_ERROR_WORD;
+    int parts[FT_MAX_BATCH], wgs = 0, max_points = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        parts[j] = c->ro_split ? std::min(std::max((counts[j] + RO_CHUNK - 1) / RO_CHUNK, 1), RO_MAX_PARTS) : 1;
+        wgs += parts[j];
+        max_points = std::max(max_points, counts[j]);
+    }
+    const bool split = wgs > n_jobs && wgs <= RO_MAX_WGS;
+    wgs = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const int g = split ? parts[j] : 1;
+        for (int k = 0; k < g; k++) o.wg_map[wgs++] = (uint32_t)j | ((uint32_t)k << 16) | ((uint32_t)g << 24);
+    }
+    if (!split && max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(wgs), dim3(512), 0, enq(c), o);   // 512: the most that leaves the hypothesis phase its 193 registers
+    else hipLaunchKernelGGL(ransac_kernel<256>, dim3(wgs), dim3(256), 0, enq(c), o);
     prof_end(c, ep);
     if (!(c->profile & 1)) c->tail_flag_seq = seq;   // (with timing on, an event record follows the launch)
 }
@@ -460,9 +492,16 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     if (hipMalloc(&p, 256) != hipSuccess) return fail(FT_E_NOMEM);
     c->done_count_dev = (unsigned*)p;
     if (hipMemset(c->done_count_dev, 0, 256) != hipSuccess) return fail(FT_E_HIP);
+    if (hipMalloc(&p, sizeof(int) * FT_MAX_BATCH * RO_MAX_HYP) != hipSuccess) return fail(FT_E_NOMEM);
+    c->ro_gcnt_dev = (int*)p;
+    if (hipMemset(c->ro_gcnt_dev, 0, sizeof(int) * FT_MAX_BATCH * RO_MAX_HYP) != hipSuccess) return fail(FT_E_HIP);
+    if (hipMalloc(&p, sizeof(unsigned) * 2 * FT_MAX_BATCH) != hipSuccess) return fail(FT_E_NOMEM);
+    c->ro_gbar_dev = (unsigned*)p;
+    if (hipMemset(c->ro_gbar_dev, 0, sizeof(unsigned) * 2 * FT_MAX_BATCH) != hipSuccess) return fail(FT_E_HIP);
+    if (const char* e = getenv("FT_RO_SPLIT")) c->ro_split = atoi(e) != 0;
     if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->done_flag_host = (unsigned*)p;
-    *c->done_flag_host = 0;
+    memset(c->done_flag_host, 0, 256);
     if (hipHostGetDevicePointer(&p, c->done_flag_host, 0) != hipSuccess) return fail(FT_E_HIP);
     c->done_flag_dev = (unsigned*)p;
 
@@ -516,6 +555,8 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->lk_norm_dev) (void)hipFree(c->lk_norm_dev);
     if (c->ingest_dev) (void)hipFree(c->ingest_dev);
     if (c->done_count_dev) (void)hipFree(c->done_count_dev);
+    if (c->ro_gcnt_dev) (void)hipFree(c->ro_gcnt_dev);
+    if (c->ro_gbar_dev) (void)hipFree(c->ro_gbar_dev);
     if (c->done_flag_host) (void)hipHostFree(c->done_flag_host);
     if (c->match_dev) (void)hipFree(c->match_dev);
     if (c->match_host) (void)hipHostFree(c->match_host);
@@ -883,9 +924,9 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         o.out_status = c->lk_out_host_dev + 12 * N;
         o.hypotheses = prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 256;
         o.seed = prm->ransac_seed;
-        int max_points = 0;
-        for (int j = 0; j < n_jobs; j++) max_points = std::max(max_points, jobs[j].n);
-        launch_reject(c, o, n_jobs, max_points);
+        int counts[FT_MAX_BATCH];
+        for (int j = 0; j < n_jobs; j++) counts[j] = jobs[j].n;
+        launch_reject(c, o, n_jobs, counts);
         FT_HIP(c, hipGetLastError());
         if (want_iters)
             FT_HIP(c, hipMemcpyAsync(c->lk_out_host + align_up(13 * N, 16), ob + align_up(13 * N, 16), sizeof(int) * N * nlev, hipMemcpyDeviceToHost, enq(c)));
@@ -954,9 +995,9 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
     o.out_status = c->lk_out_host_dev + 12 * N;
     o.hypotheses = hypotheses > 0 ? hypotheses : 256;
     o.seed = seed;
-    int max_points = 0;
-    for (int j = 0; j < n_sets; j++) max_points = std::max(max_points, sets[j].n);
-    launch_reject(c, o, n_sets, max_points);
+    int counts[FT_MAX_BATCH];
+    for (int j = 0; j < n_sets; j++) counts[j] = sets[j].n;
+    launch_reject(c, o, n_sets, counts);
     FT_HIP(c, hipGetLastError());
     PendingLK& P = c->lk_pending;
     P.jobs = std::move(deliver);

@@ -7,7 +7,11 @@
 // is the build's own (a counter-based hash); model, error measure and threshold are OpenCV's.  The arithmetic is
 // double precision in a fixed order, so the result equals the CPU checker's bit for bit.
 //
-// One launch per batch of image pairs, one workgroup per pair (ransac_kernel).  Hypotheses are tried in index order in
+// One launch per batch of image pairs (ransac_kernel).  A pair of up to RO_CHUNK points has one workgroup; a larger one
+// has ceil(n / RO_CHUNK) of them (its "parts"), each owning a contiguous chunk of the points: every part builds the same
+// hypotheses (the arithmetic is deterministic, so nothing has to be handed over), counts the inliers among its own
+// points, adds its counts to the pair's counters in device memory, and after a barrier among the pair's parts every part
+// reads the same totals and takes the same decisions.  Hypotheses are tried in index order in
 // rounds of 32.  A hypothesis is solved by eight lanes, one per equation of the 8x9 system, each holding its row in
 // registers; pivot search and the pivot row travel by lane shuffles, so the elimination touches no memory.  The inlier
 // counts of a round's 32 models are shared by all 256 threads (32 models x 8 slices of the point set, points read from
@@ -37,6 +41,13 @@ struct OutlierArgs {
     unsigned* done_count;      // device, zero between launches
     unsigned* done_flag;
     unsigned done_seq;
+    // pairs with more than one workgroup: inlier totals [pair][RO_MAX_HYP], and per pair {barrier arrivals, finished
+    // parts} (device, zero between launches); error word in pinned host memory (set if a barrier gave up)
+    int* gcnt;
+    unsigned* gbar;
+    unsigned* error_flag;
+    // workgroup -> pair | part << 16 | parts << 24
+    uint32_t wg_map[FT_MAX_BATCH];
 };
 
 __device__ __forceinline__ uint32_t ro_mix32(uint32_t x) {
@@ -83,6 +94,24 @@ __device__ __forceinline__ bool ro_inlier(const double* F, float4 m, float thr2)
 constexpr int RO_HYP_PER_WG = 32;     // hypotheses per round (8 lanes each)
 constexpr int RO_SUB = 4;             // models whose inliers are counted together (a power of two)
 constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest is read from the global copy
+constexpr int RO_MAX_HYP = 256;       // upper bound of OutlierArgs::hypotheses
+constexpr int RO_CHUNK = 512;         // points per workgroup of a pair that is split into parts
+constexpr int RO_MAX_PARTS = 32;      // parts per pair at most (larger pairs get larger chunks)
+constexpr int RO_MAX_WGS = FT_MAX_BATCH;   // workgroups per launch when pairs are split: all of them fit the device at once
+constexpr unsigned RO_SPIN_LIMIT = 1u << 20;   // barrier polls before a part gives up (a fraction of a second)
+
+// Barrier among the `parts` workgroups of one pair, called by one thread per workgroup after a workgroup barrier.  The
+// k-th barrier of the launch is passed when parts * (k + 1) arrivals have been counted.  All parts of a launch are
+// resident at once (the host never launches more split workgroups than the device holds), so every arrival comes;
+// the poll count is bounded all the same, and a part that gives up reports it instead of hanging the queue.
+__device__ inline bool ro_pair_barrier(unsigned* bar, unsigned target) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 0; spins < RO_SPIN_LIMIT; spins++) {
+        if (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
 
 // Hypotheses to try before a sample of eight inliers has been drawn with probability 0.999, given the best model so far
 // has `inliers` of n points: the smallest N with (1 - w^8)^N <= 0.001, at most max_h.  Plain multiplications in a fixed
@@ -111,24 +140,33 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
     __shared__ double best_F[9];
     __shared__ int valid[RO_HYP_PER_WG];
     __shared__ int cnt[RO_HYP_PER_WG];
-    __shared__ int s_stop, s_best, s_have;
+    __shared__ int s_stop, s_best, s_have, s_abort;
     const int t = threadIdx.x;
-    const LKJobDev* job = a.jobs + blockIdx.x;
+    const uint32_t wm = a.wg_map[blockIdx.x];
+    const int pair = (int)(wm & 0xffffu), part = (int)((wm >> 16) & 0xffu), parts = (int)(wm >> 24);
+    const LKJobDev* job = a.jobs + pair;
     const int first = job->first, n = job->count;
+    // this workgroup's points [lo, hi) of the pair
+    const int chunk = (n + parts - 1) / parts;
+    const int lo = part * chunk, hi = min(n, lo + chunk), own = max(hi - lo, 0);
+    int* const gcnt = a.gcnt + (size_t)pair * RO_MAX_HYP;
+    unsigned* const gbar = a.gbar + 2 * (size_t)pair;
+    unsigned barriers = 0;   // passed so far (same in every part: they take the same decisions)
     const double* c0 = job->calib;        // template image camera
     const double* c1 = job->calib + 8;    // target image camera
     const double f0 = c0[0] < c0[1] ? c0[1] : c0[0], f1 = c1[0] < c1[1] ? c1[1] : c1[0];
     const float thr = (float)(1. / (f0 < f1 ? f1 : f0)), thr2 = thr * thr;
 
-    // ---- normalized coordinates of both point sets ----
-    for (int i = t; i < n; i += T) {
-        const float2 p = ro_undistort(a.prev_xy[2 * (first + i)], a.prev_xy[2 * (first + i) + 1], c0);
-        const float2 q = ro_undistort(a.next_xy[2 * (first + i)], a.next_xy[2 * (first + i) + 1], c1);
+    // ---- normalized coordinates of both point sets (own points; index relative to lo) ----
+    for (int i = t; i < own; i += T) {
+        const int g = first + lo + i;
+        const float2 p = ro_undistort(a.prev_xy[2 * g], a.prev_xy[2 * g + 1], c0);
+        const float2 q = ro_undistort(a.next_xy[2 * g], a.next_xy[2 * g + 1], c1);
         const float4 m = make_float4(p.x, p.y, q.x, q.y);
         if (i < RO_NORM_LDS) nl[i] = m;
-        else a.norm[first + i] = m;
+        else a.norm[g] = m;
     }
-    if (t == 0) { s_stop = n < 8 ? 0 : a.hypotheses; s_best = 7; s_have = 0; }   // a model needs at least 8 inliers
+    if (t == 0) { s_stop = n < 8 ? 0 : a.hypotheses; s_best = 7; s_have = 0; s_abort = 0; }   // a model needs at least 8 inliers
     __syncthreads();   // also orders this workgroup's global writes above before its reads below
 
     for (int h0 = 0; h0 < s_stop; h0 += RO_HYP_PER_WG) {   // s_stop only changes between the barriers at the loop's end
@@ -160,7 +198,15 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) mine = (r == k) ? idx[k] : mine;
             }
-            const float4 m = mine < RO_NORM_LDS ? nl[mine] : a.norm[first + mine];
+            // the sample may belong to another part: normalized here from the raw positions (the same arithmetic as
+            // above, so the same value); a pair with one workgroup has it in its own copy
+            float4 m;
+            if (parts == 1) m = mine < RO_NORM_LDS ? nl[mine] : a.norm[first + mine];
+            else {
+                const float2 p = ro_undistort(a.prev_xy[2 * (first + mine)], a.prev_xy[2 * (first + mine) + 1], c0);
+                const float2 q = ro_undistort(a.next_xy[2 * (first + mine)], a.next_xy[2 * (first + mine) + 1], c1);
+                m = make_float4(p.x, p.y, q.x, q.y);
+            }
             const double x1 = m.x, y1 = m.y, x2 = m.z, y2 = m.w;
             double A[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.};
             uint32_t colmask = 0;
@@ -250,11 +296,21 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
 #pragma unroll
                     for (int q = 0; q < 9; q++) F[q] = Fs[hh][q];
                     int c = 0;
-                    for (int i = slice; i < n; i += T / RO_SUB) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + i], thr2) ? 1 : 0;
+                    for (int i = slice; i < own; i += T / RO_SUB) c += ro_inlier(F, i < RO_NORM_LDS ? nl[i] : a.norm[first + lo + i], thr2) ? 1 : 0;
                     if (c) atomicAdd(&cnt[hh], c);
                 }
             }
             __syncthreads();
+            if (parts > 1) {
+                // own counts to the pair's totals, barrier among the parts, totals back (every part reads the same)
+                if (t < RO_SUB && cnt[q0 + t]) atomicAdd(&gcnt[h0 + q0 + t], cnt[q0 + t]);
+                __syncthreads();
+                if (t == 0) {
+                    barriers++;
+                    if (!ro_pair_barrier(gbar, (unsigned)parts * barriers)) s_abort = 1;
+                    for (int q = q0; q < q0 + RO_SUB; q++) cnt[q] = __hip_atomic_load(&gcnt[h0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             // as a sequential loop over hypotheses would see them
             if (t == 0) {
                 int stop = s_stop, best = s_best;
@@ -266,16 +322,28 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
                     const int need = ro_hypotheses_needed(best, n, a.hypotheses);
                     stop = need < stop ? need : stop;
                 }
-                s_stop = stop; s_best = best;
+                s_stop = s_abort ? 0 : stop; s_best = best;
             }
             __syncthreads();
         }
     }
 
     // ---- final mask and the batch results into the pinned host block ----
-    const bool have_model = s_have != 0;
-    for (int i = t; i < n; i += T) {
-        const int g = first + i;
+    const bool have_model = s_have != 0 && !s_abort;
+    if (s_abort && t == 0) *reinterpret_cast<volatile unsigned*>(a.error_flag) = 1u;
+    if (parts > 1) {
+        // the last part of the pair to get here leaves the pair's counters at zero for the next launch (every part has
+        // passed its last barrier and read its last totals by then)
+        __shared__ unsigned s_last;
+        if (t == 0) s_last = __hip_atomic_fetch_add(&gbar[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)parts - 1;
+        __syncthreads();
+        if (s_last) {
+            for (int i = t; i < RO_MAX_HYP; i += T) gcnt[i] = 0;
+            if (t < 2) gbar[t] = 0;
+        }
+    }
+    for (int i = t; i < own; i += T) {
+        const int g = first + lo + i;
         const bool keep = have_model && a.status[g] && ro_inlier(best_F, i < RO_NORM_LDS ? nl[i] : a.norm[g], thr2);
         a.out_xy[2 * g] = a.next_xy[2 * g];
         a.out_xy[2 * g + 1] = a.next_xy[2 * g + 1];
@@ -289,7 +357,7 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __syncthreads();
         if (t == 0) {
-            const unsigned finished = atomicAdd(a.done_count, 1u);
+            const unsigned finished = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if (finished == gridDim.x - 1) {   // every other workgroup's stores have been acknowledged
                 *a.done_count = 0;
                 __threadfence_system();

@@ -46,6 +46,14 @@ public:
         hot_ts->push_back(timestamp);
     }
 
+    // pull the three list headers that prefetch_tail and append read (they live in the maps' nodes)
+    void prefetch_lists(size_t cam_id) const {
+        if (!hot_ts || hot_cam != cam_id) return;
+        __builtin_prefetch(hot_uv, 1);
+        __builtin_prefetch(hot_uvn, 1);
+        __builtin_prefetch(hot_ts, 1);
+    }
+
     // pull the cache lines the next append(cam_id, ...) will write (no effect on the contents)
     void prefetch_tail(size_t cam_id) const {
         if (!hot_ts || hot_cam != cam_id) return;

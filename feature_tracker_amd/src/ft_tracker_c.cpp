@@ -103,8 +103,16 @@ struct ftk_group {
         long long tracked = 0, attempted = 0;
         int rc = FT_OK;
     };
-    static constexpr int MAIL_RING = 4;          // power of two, >= PIPE_DEPTH + 2
-    static constexpr int PIPE_DEPTH = 2;         // sets that may be in flight behind the one the caller collects
+    static constexpr int MAIL_RING = 8;          // power of two, >= pipe_depth() + 2
+    // sets that may be in flight behind the one the caller collects (FT_PIPE_DEPTH overrides it, 1..6)
+    static int pipe_depth() {
+        static const int d = [] {
+            const char* e = getenv("FT_PIPE_DEPTH");
+            const int v = e ? atoi(e) : 3;   // 3: the 3840x2160 single stream holds its rate from region to region (2: -10 % in two of three)
+            return v < 1 ? 1 : (v > MAIL_RING - 2 ? MAIL_RING - 2 : v);
+        }();
+        return d;
+    }
     Mail mail[MAIL_RING];
     std::atomic<int> spin_us{20};   // how long a waiting side polls before it goes to sleep (microseconds)
     std::thread driver;
@@ -309,9 +317,10 @@ struct ftk_group {
             M.tracked = (long long)batch->tracked_features();
             M.attempted = (long long)batch->attempted_features();
             const bool more = posted.load(std::memory_order_acquire) > next;
-            if (late_detect && !more) {
-                // one set at a time: a hundred or so observations are written faster here than a writer thread wakes up
-                if (n > 4) {
+            if (late_detect && !more && spin_us.load(std::memory_order_relaxed) > 100) {
+                // one set at a time, and the caller waits for it (the synchronous feed and flush set the long spin): a
+                // hundred or so observations are written faster here than a writer thread wakes up
+                if (n > 4 || batch->tracker(0).get_num_features() >= 1024) {
                     write_db_together();   // thousands of observations: shared with the writer threads
                 } else {
                     wait_db();             // (sets handed to the writers earlier come first)
@@ -612,7 +621,7 @@ int ftk_batch_feed_pipelined(ftk_batch* b, const double* timestamps, const void*
                              size_t stride, long long* tracked, long long* attempted) {
     if (!b || !timestamps || !frames || w < 1 || h < 1) return FT_E_INVALID;
     long long tr = 0, at = 0;
-    const long depth = ftk_group::PIPE_DEPTH;
+    const long depth = ftk_group::pipe_depth();
     for (auto& g : b->groups) g->spin_us.store(20, std::memory_order_relaxed);     // throughput matters: leave the cores to the workers
     int rc = b->collect(b->seq - depth, tr, at);   // keeps the mailbox ring from wrapping onto a set still in use
     if (rc != FT_OK) return rc;

@@ -22,7 +22,11 @@ public:
     TrackBase() : database(new FeatureDatabase()), propagator(new TrackPropagator()), num_features(200), currid(0) {}
     // numaruco: ids start above the ArUco tag range (TrackBase.h:86-89)
     TrackBase(int numfeats, int numaruco)
-        : database(new FeatureDatabase()), propagator(new TrackPropagator()), num_features(numfeats), currid((size_t)numaruco + 1) {}
+        : database(new FeatureDatabase()), propagator(new TrackPropagator()), num_features(numfeats), currid((size_t)numaruco + 1) {
+        // thousands of observations per frame: the database is split by feature id so that several host threads can
+        // write one frame's observations side by side
+        if (numfeats >= 1024) database->set_shards(4);
+    }
     virtual ~TrackBase() = default;
 
     // camera_calib: fx,fy,cx,cy,d1..d4 per camera; camera_extrinsics: 4x4 T_cam_imu per camera (TrackBase.h:99-215)

@@ -222,25 +222,29 @@ void TrackKLT::set_cached_detection(const Detection& det) {
     }
 }
 
-void TrackKLT::mono_commit(MonoPlan& plan) {
+void TrackKLT::mono_commit(MonoPlan& plan, int part, int parts) {
     if (!plan.db_pending) return;
-    plan.db_pending = false;
-    // raw pixel -> normalized coordinates (TrackKLT.cpp:187-192); calibration is read-only while frames are fed
+    if (parts == 1) plan.db_pending = false;   // (threads that share a plan leave it alone: it is set anew for every frame)
+    // raw pixel -> normalized coordinates (TrackKLT.cpp:187-192); calibration is read-only while frames are fed.
+    // Every thread converts the observations it is going to write.
     const std::array<double, 4>& K = camera_k.at(plan.cam);
     const std::array<double, 4>& Dc = camera_d.at(plan.cam);
+    const size_t n = plan.db_ids.size();
     if (Dc[0] == 0. && Dc[1] == 0. && Dc[2] == 0. && Dc[3] == 0.) {   // no distortion: the same arithmetic without the iteration
         const double ifx = 1. / K[0], ify = 1. / K[1];
-        for (size_t i = 0; i < plan.db_ids.size(); i++) {
+        for (size_t i = 0; i < n; i++) {
+            if (parts > 1 && database->owner_of(plan.db_ids[i], parts) != part) continue;
             plan.db_uvn[4 * i + 2] = (float)(((double)plan.db_uvn[4 * i] - K[2]) * ifx);
             plan.db_uvn[4 * i + 3] = (float)(((double)plan.db_uvn[4 * i + 1] - K[3]) * ify);
         }
     } else {
-        for (size_t i = 0; i < plan.db_ids.size(); i++) {
+        for (size_t i = 0; i < n; i++) {
+            if (parts > 1 && database->owner_of(plan.db_ids[i], parts) != part) continue;
             const Point2f npt = undistort_point_brown(Point2f(plan.db_uvn[4 * i], plan.db_uvn[4 * i + 1]), K, Dc);
             plan.db_uvn[4 * i + 2] = npt.x; plan.db_uvn[4 * i + 3] = npt.y;
         }
     }
-    database->update_features(plan.db_ids.size(), plan.db_ids.data(), plan.timestamp, plan.cam, plan.db_uvn.data());
+    database->update_features(n, plan.db_ids.data(), plan.timestamp, plan.cam, plan.db_uvn.data(), part, parts);
 }
 
 int TrackKLT::abort_feed(int rc, size_t cam_a, size_t cam_b) {

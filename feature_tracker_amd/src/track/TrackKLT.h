@@ -101,7 +101,9 @@ public:
     void mono_finish(MonoPlan& plan, const Detection& cur_det);
     // 4. ... and written to the feature database here (src/track/TrackKLT.cpp:187-198).  Nothing in the next frame's
     //    tracking depends on it, so a driver may run it while the device works on the next frame.
-    void mono_commit(MonoPlan& plan);
+    // (part, parts): `parts` threads may commit one plan together, thread `part` writing the observations whose ids it owns
+    // (FeatureDatabase::owner_of)
+    void mono_commit(MonoPlan& plan, int part = 0, int parts = 1);
     // the ranked detection of the last frame, for a driver whose detector finishes after mono_finish (which then got
     // an invalid detection)
     void set_cached_detection(const Detection& det);

@@ -75,10 +75,16 @@ public:
     }
     // apply observations taken with take_db; reads the (fixed) calibration and writes the feature databases, which carry their own locks, so it
     // may run on another thread than begin()/complete() as long as one stream's sets are applied in order
-    // (part, parts): apply only the streams s with s % parts == part, so that several threads can share one payload
+    // (part, parts): several threads can share one payload.  With at least as many streams as threads, thread `part`
+    // applies the streams s with s % parts == part; with fewer (a few large streams), every thread applies its share of
+    // every stream's observations (split by feature id, see FeatureDatabase::owner_of).
     void commit_db(std::vector<TrackKLT::MonoPlan>& payload, int part = 0, int parts = 1) {
         // a plain loop on purpose: the worker pool belongs to the thread that runs begin()/complete()
-        for (size_t s = (size_t)part; s < payload.size(); s += (size_t)parts) trackers[s]->mono_commit(payload[s]);
+        if (parts == 1 || payload.size() >= (size_t)parts) {
+            for (size_t s = (size_t)part; s < payload.size(); s += (size_t)parts) trackers[s]->mono_commit(payload[s]);
+        } else {
+            for (size_t s = 0; s < payload.size(); s++) trackers[s]->mono_commit(payload[s], part, parts);
+        }
     }
     bool in_flight() const { return pending; }
 

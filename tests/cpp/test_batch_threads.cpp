@@ -30,6 +30,7 @@ struct Run {
     std::vector<std::vector<float>> xy;           // per stream, after the last frame
     std::vector<std::vector<uint64_t>> ids;
     std::vector<int> db;
+    std::vector<std::vector<float>> tracks;       // per stream: every observation of every live feature, in id order
 };
 
 int main() {
@@ -44,10 +45,13 @@ int main() {
     }
     const double calib8[8] = {120., 120., W / 2., H / 2., 0., 0., 0., 0.};
 
-    auto run = [&](int groups, bool pipelined) {
+    // n_streams <= S streams; num_pts >= 1024 makes the trackers split their feature databases by id, and with fewer
+    // streams than writer threads the writers then share every frame's observations of a stream
+    auto run = [&](int groups, bool pipelined, int n_streams = 8, int num_pts = 60) {
+        const int S = n_streams;
         ftk_options o;
         ftk_default_options(&o);
-        o.num_pts = 60; o.grid_x = 3; o.grid_y = 2; o.min_px_dist = 6; o.win_size = 9; o.pyr_levels = 2;
+        o.num_pts = num_pts; o.grid_x = 3; o.grid_y = 2; o.min_px_dist = num_pts > 1000 ? 2 : 6; o.win_size = 9; o.pyr_levels = 2;
         ftk_batch* b = nullptr;
         CHECK(ftk_batch_create_grouped(&b, 0, &o, S, W, H, groups, 0) == 0);
         for (int s = 0; s < S; s++) CHECK(ftk_batch_set_calibration(b, s, calib8, nullptr) == 0);
@@ -66,13 +70,23 @@ int main() {
         if (pipelined) { long long tr = 0, at = 0; CHECK(ftk_batch_flush(b, &tr, &at) == 0); total += tr; }
         r.tracked.push_back(total);
         for (int s = 0; s < S; s++) {
-            std::vector<float> xy(2 * 256);
-            std::vector<uint64_t> ids(256);
-            const int n = ftk_batch_get_points(b, s, xy.data(), ids.data(), 256);
-            CHECK(n >= 0);
+            std::vector<float> xy(2 * 2048);
+            std::vector<uint64_t> ids(2048);
+            const int n = ftk_batch_get_points(b, s, xy.data(), ids.data(), 2048);
+            CHECK(n >= 0 && n <= 2048);
             xy.resize(2 * (size_t)n); ids.resize((size_t)n);
             r.xy.push_back(xy); r.ids.push_back(ids);
             r.db.push_back(ftk_batch_database_size(b, s));
+            std::vector<float> tr;
+            for (uint64_t id : ids) {
+                float uvn[4 * 64];
+                double ts[64];
+                const int m = ftk_batch_get_track(b, s, id, uvn, ts, 64);
+                CHECK(m >= 0 && m <= 64);
+                tr.push_back((float)m);
+                for (int k = 0; k < m; k++) { tr.insert(tr.end(), uvn + 4 * k, uvn + 4 * k + 4); tr.push_back((float)ts[k]); }
+            }
+            r.tracks.push_back(tr);
         }
         ftk_batch_destroy(b);
         return r;
@@ -91,6 +105,21 @@ int main() {
             CHECK(r->ids[(size_t)s] == plain.ids[(size_t)s]);
             CHECK(r->xy[(size_t)s] == plain.xy[(size_t)s]);
             CHECK(r->db[(size_t)s] == plain.db[(size_t)s]);
+            CHECK(r->tracks[(size_t)s] == plain.tracks[(size_t)s]);
+        }
+    }
+    // one and two large streams in one group: databases split by id, every frame's observations written by the two
+    // writer threads (and the driver, for the last set) together
+    for (int n_streams : {1, 2}) {
+        const Run big_plain = run(1, false, n_streams, 1200);
+        const Run big_piped = run(1, true, n_streams, 1200);
+        long long big_total = 0;
+        for (size_t i = 0; i + 1 < big_plain.tracked.size(); i++) big_total += big_plain.tracked[i];
+        CHECK(big_total > 1000 && big_piped.tracked.back() == big_total);
+        for (int s = 0; s < n_streams; s++) {
+            CHECK(big_piped.ids[(size_t)s] == big_plain.ids[(size_t)s] && big_piped.xy[(size_t)s] == big_plain.xy[(size_t)s]);
+            CHECK(big_piped.db[(size_t)s] == big_plain.db[(size_t)s] && big_piped.db[(size_t)s] > 100);
+            CHECK(big_piped.tracks[(size_t)s] == big_plain.tracks[(size_t)s]);
         }
     }
     std::printf("%d checks passed, %lld features tracked\n", checks, plain_total);

@@ -15,9 +15,14 @@ using namespace feature_tracker;
         if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
     } while (0)
 
-int main() {
+#include <thread>
+
+// shards: how many shards database `a` is split into (b stays the reference's single map); writers: threads that
+// share every batched update of `a`
+static int run(int shards, int writers) {
     // 1. batched == one by one, over many frames with ids appearing and disappearing
     FeatureDatabase a, b;
+    CHECK(a.set_shards(shards) && a.shard_count() == shards);
     for (int frame = 0; frame < 300; frame++) {
         std::vector<size_t> ids;
         std::vector<float> uvn;
@@ -28,7 +33,13 @@ int main() {
             uvn.insert(uvn.end(), {u, v, u * 0.01f, v * 0.01f});
         }
         const double t = 100.0 + 0.05 * frame;
-        a.update_features(ids.size(), ids.data(), t, 0, uvn.data());
+        if (writers == 1) a.update_features(ids.size(), ids.data(), t, 0, uvn.data());
+        else {
+            std::vector<std::thread> th;
+            for (int p = 0; p < writers; p++) th.emplace_back([&, p] { a.update_features(ids.size(), ids.data(), t, 0, uvn.data(), p, writers); });
+            for (auto& x : th) x.join();
+        }
+        if (frame == 0) CHECK(!a.set_shards(2));   // not once features exist
         for (size_t i = 0; i < ids.size(); i++) b.update_feature(ids[i], t, 0, uvn[4 * i], uvn[4 * i + 1], uvn[4 * i + 2], uvn[4 * i + 3]);
     }
     CHECK(a.size() == b.size() && a.size() > 200);
@@ -93,11 +104,30 @@ int main() {
     CHECK(a.size() == n_before - 1 && a.get_feature(first_id) == nullptr);
     size_t some = 0;
     for (const auto& kv : a.get_internal_data()) { some = kv.first; break; }
-    a.rekey(some, 1000000);
-    CHECK(a.get_feature(some) == nullptr && a.get_feature(1000000) != nullptr && a.get_feature(1000000)->featid == 1000000);
-    Feature* f = a.get_feature(1000000);
+    // (with several shards the new id lives in another shard than the old one: 1000001 - some is odd or even as needed)
+    const size_t new_id = 1000000 + ((some % 4) == 0 ? 1 : 0);
+    const size_t n_obs = a.get_feature(some)->num_measurements();
+    a.rekey(some, new_id);
+    CHECK(a.get_feature(some) == nullptr && a.get_feature(new_id) != nullptr && a.get_feature(new_id)->featid == new_id);
+    CHECK(a.get_feature(new_id)->num_measurements() == n_obs);
+    const size_t ids1[1] = {new_id};
+    const float uvn1[4] = {1, 2, 3, 4};
+    a.update_features(1, ids1, 1e6, 0, uvn1);                // the moved feature keeps growing in its new shard
+    CHECK(a.get_feature(new_id)->num_measurements() == n_obs + 1);
+    // re-keying onto an id that is taken leaves that feature in place (insert semantics, src/track/TrackBase.h:264)
+    size_t other = 0;
+    for (const auto& kv : a.get_internal_data()) if (kv.first != new_id) { other = kv.first; break; }
+    const size_t other_obs = a.get_feature(other)->num_measurements(), n_now = a.size();
+    a.rekey(new_id, other);
+    CHECK(a.size() == n_now - 1 && a.get_feature(new_id) == nullptr && a.get_feature(other)->num_measurements() == other_obs);
+    Feature* f = a.get_feature(other);
     f->clean_old_measurements({f->timestamps.at(0).front()});
     CHECK(f->num_measurements() == 1);
-    std::printf("feature database checks passed (%zu features)\n", a.size());
+    std::printf("feature database checks passed (%zu features, %d shard(s), %d writer(s))\n", a.size(), shards, writers);
+    return 0;
+}
+
+int main() {
+    if (run(1, 1) || run(4, 1) || run(4, 3) || run(3, 2) || run(1, 2)) return 1;
     return 0;
 }

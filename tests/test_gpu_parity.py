@@ -392,6 +392,54 @@ def test_reject_outliers_equals_oracle(dev, n, n_out, seed):
     assert sum(int(w_.sum()) for w_ in want) > 0
 
 
+@pytest.mark.parametrize("sizes,n_out_frac,hyp", [((513, 150, 1024, 1025, 7, 2600), 0.3, 256), ((9000,), 0.05, 256), ((1500, 1500, 40), 0.75, 256),
+                                                  ((17000, 600), 0.2, 64)])
+def test_reject_outliers_split_pairs_equal_oracle(dev, sizes, n_out_frac, hyp):
+    """Pairs of more than 512 points are spread over several workgroups that meet at a barrier after every group of
+    four models: sizes around the chunk boundaries, small pairs in the same launch, many outliers (many rounds before
+    the search stops, or no model at all), a pair beyond 32 chunks.  The masks equal the CPU checker's."""
+    sets, want = [], []
+    for k, n in enumerate(sizes):
+        calib = CALIBS[k % 2]
+        prev, nxt, _ = synth.two_view_matches(n, int(n * n_out_frac), calib, seed=100 + k)
+        status = (np.random.default_rng(k).random(n) > 0.05).astype(np.uint8)
+        sets.append(dict(prev_xy=prev, next_xy=nxt, status=status, calib_prev=calib))
+        want.append(O.reject_outliers(prev, nxt, status, calib, calib, hypotheses=hyp, seed=7)[0])
+    with _ctx(dev, 64, 64, max_points=sum(sizes) + 16) as ctx:
+        for _ in range(2):                                                   # the second launch finds the counters as the first left them
+            got = ctx.reject_outliers(sets, hypotheses=hyp, seed=7)
+            for g, w_ in zip(got, want):
+                assert np.array_equal(g, w_)
+
+
+def test_reject_outliers_more_parts_than_the_device_holds(dev, monkeypatch):
+    """A launch whose split pairs would need more than 256 workgroups runs one workgroup per pair instead, and
+    FT_RO_SPLIT=0 does so always: same masks either way."""
+    calib = CALIBS[1]
+    sets, want = [], []
+    for k in range(90):
+        n = 1100 if k % 2 == 0 else 30
+        prev, nxt, _ = synth.two_view_matches(n, n // 5, calib, seed=300 + k)
+        sets.append(dict(prev_xy=prev, next_xy=nxt, calib_prev=calib))
+    want = [O.reject_outliers(q["prev_xy"], q["next_xy"], np.ones(len(q["prev_xy"]), np.uint8), calib, calib, hypotheses=32, seed=1)[0] for q in sets[:6]]
+    with _ctx(dev, 64, 64, max_points=60000) as ctx:
+        got = ctx.reject_outliers(sets, hypotheses=32, seed=1)               # 45 * 3 + 45 = 180 workgroups: split
+        got_few = ctx.reject_outliers(sets[:6], hypotheses=32, seed=1)
+    monkeypatch.setenv("FT_RO_SPLIT", "0")
+    with _ctx(dev, 64, 64, max_points=60000) as ctx:
+        got_one = ctx.reject_outliers(sets, hypotheses=32, seed=1)
+    big = [dict(prev_xy=np.tile(q["prev_xy"], (3, 1)), next_xy=np.tile(q["next_xy"], (3, 1)), calib_prev=calib) for q in sets[:80:2]]
+    monkeypatch.delenv("FT_RO_SPLIT")
+    with _ctx(dev, 64, 64, max_points=140000) as ctx:
+        got_big = ctx.reject_outliers(big, hypotheses=32, seed=1)            # 40 * 7 = 280 workgroups: not split
+    for i in range(6):
+        assert np.array_equal(got[i], want[i]) and np.array_equal(got_few[i], want[i])
+    for a, b in zip(got, got_one):
+        assert np.array_equal(a, b)
+    w0 = O.reject_outliers(big[0]["prev_xy"], big[0]["next_xy"], np.ones(3300, np.uint8), calib, calib, hypotheses=32, seed=1)[0]
+    assert np.array_equal(got_big[0], w0)
+
+
 def test_reject_outliers_degenerate_sets(dev):
     calib = CALIBS[0]
     prev, nxt, _ = synth.two_view_matches(100, 0, calib, seed=5)
