@@ -31,6 +31,7 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int FT_RO_DEFAULT_HYP = 1000;   // OpenCV's iteration limit for findFundamentalMat(FM_RANSAC)
 constexpr int FT_RO_ERROR_WORD = 16;   // word of the pinned completion-flag block that the rejection kernel sets when a barrier gave up
 
 struct SlotState {
@@ -87,6 +88,7 @@ struct ft_ctx {
     int* ro_gcnt_dev = nullptr;          // outlier rejection, pairs split over workgroups: inlier totals [pair][RO_MAX_HYP]
     unsigned* ro_gbar_dev = nullptr;     // ... and per pair {barrier arrivals, finished parts}; both zero between launches
     bool ro_split = true;                // FT_RO_SPLIT=0: one workgroup per pair whatever its size
+    bool use_done_flag = true;           // FT_DONE_FLAG=0: every fence records an event; the kernel's completion flag is not used
     uint32_t done_seq = 0;               // last sequence number handed to a launch
     uint32_t tail_flag_seq = 0;          // != 0: the newest work on the queue is the launch that stores this number
     ArenaDesc arena{};
@@ -291,7 +293,7 @@ void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, const int* counts) {
     EventPair ep;
     prof_begin(c, 3, ep);
     const uint32_t seq = ++c->done_seq ? c->done_seq : ++c->done_seq;   // never 0
-    o.done_count = c->done_count_dev; o.done_flag = c->done_flag_dev; o.done_seq = seq;
+    o.done_count = c->done_count_dev; o.done_flag = c->use_done_flag ? c->done_flag_dev : nullptr; o.done_seq = seq;
     o.gcnt = c->ro_gcnt_dev; o.gbar = c->ro_gbar_dev; o.error_flag = c->done_flag_dev + FT_RO_ERROR_WORD;
     int parts[FT_MAX_BATCH], wgs = 0, max_points = 0;
     for (int j = 0; j < n_jobs; j++) {
@@ -308,7 +310,7 @@ void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, const int* counts) {
     if (!split && max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(wgs), dim3(512), 0, enq(c), o);   // 512: the most that leaves the hypothesis phase its 193 registers
     else hipLaunchKernelGGL(ransac_kernel<256>, dim3(wgs), dim3(256), 0, enq(c), o);
     prof_end(c, ep);
-    if (!(c->profile & 1)) c->tail_flag_seq = seq;   // (with timing on, an event record follows the launch)
+    if (!(c->profile & 1) && c->use_done_flag) c->tail_flag_seq = seq;   // (with timing on, an event record follows the launch)
 }
 
 int pick_seglen(int win_w, int win_h) {
@@ -499,6 +501,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->ro_gbar_dev = (unsigned*)p;
     if (hipMemset(c->ro_gbar_dev, 0, sizeof(unsigned) * 2 * FT_MAX_BATCH) != hipSuccess) return fail(FT_E_HIP);
     if (const char* e = getenv("FT_RO_SPLIT")) c->ro_split = atoi(e) != 0;
+    if (const char* e = getenv("FT_DONE_FLAG")) c->use_done_flag = atoi(e) != 0;
     if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->done_flag_host = (unsigned*)p;
     memset(c->done_flag_host, 0, 256);
@@ -772,7 +775,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     if (!seglen) return FT_E_INVALID;
     const bool fb = (prm->flags & FT_LK_FORWARD_BACKWARD) != 0;
     const bool reject = (prm->flags & FT_LK_REJECT_OUTLIERS) != 0;
-    if (reject && (prm->ransac_hypotheses < 0 || prm->ransac_hypotheses > 256)) return FT_E_INVALID;
+    if (reject && (prm->ransac_hypotheses < 0 || prm->ransac_hypotheses > RO_MAX_HYP)) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
     if (c->lk_pending.active) {   // staging is single-buffered: finish the previous batch first
         int rc = sync_and_deliver(c);
@@ -922,7 +925,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
         o.out_xy = reinterpret_cast<float*>(c->lk_out_host_dev);
         o.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);
         o.out_status = c->lk_out_host_dev + 12 * N;
-        o.hypotheses = prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 256;
+        o.hypotheses = prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : FT_RO_DEFAULT_HYP;
         o.seed = prm->ransac_seed;
         int counts[FT_MAX_BATCH];
         for (int j = 0; j < n_jobs; j++) counts[j] = jobs[j].n;
@@ -943,7 +946,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 }
 
 int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed) {
-    if (!c || !sets || n_sets < 1 || n_sets > FT_MAX_BATCH || hypotheses < 0 || hypotheses > 256) return FT_E_INVALID;
+    if (!c || !sets || n_sets < 1 || n_sets > FT_MAX_BATCH || hypotheses < 0 || hypotheses > RO_MAX_HYP) return FT_E_INVALID;
     size_t N = 0;
     for (int j = 0; j < n_sets; j++) {
         const ft_match_set& S = sets[j];
@@ -993,7 +996,7 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
     o.out_xy = reinterpret_cast<float*>(c->lk_out_host_dev);
     o.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);
     o.out_status = c->lk_out_host_dev + 12 * N;
-    o.hypotheses = hypotheses > 0 ? hypotheses : 256;
+    o.hypotheses = hypotheses > 0 ? hypotheses : FT_RO_DEFAULT_HYP;
     o.seed = seed;
     int counts[FT_MAX_BATCH];
     for (int j = 0; j < n_sets; j++) counts[j] = sets[j].n;

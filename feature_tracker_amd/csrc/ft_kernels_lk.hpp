@@ -823,18 +823,14 @@ __device__ __forceinline__ void lk_write_result(const LKArgs& a, int pt, const L
 }
 #undef LK_WAVE_LOCALS
 
-// One wavefront per feature.  SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more staged rows per lane)
+// All levels of one feature on one wavefront.  SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more
+// staged rows per lane).  jlds / ilds: the wavefront's LDS arrays for the target and the template region.
 template <int SEGLEN, bool TALL>
-__global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
+__device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, uint32_t* __restrict__ jlds, uint32_t* __restrict__ ilds) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
     constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
-    __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region (+ a row for the staging's surplus rows, + slack: row reads are dword-granular)
-    __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: window + Scharr apron
-    const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
-    if (pt >= a.total) return;
-    const int lane = threadIdx.x;
     LkWave<SEGLEN> W;
     LkPoint P;
     lk_prologue<SEGLEN>(a, pt, lane, W, P);
@@ -892,6 +888,25 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
         __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
     }
     if (lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
+}
+
+// One wavefront per feature, one single-wavefront workgroup each: the hardware dispatcher hands a free wave slot its
+// next feature.  Measured against resident wavefronts that loop over features (9 531 features, 21 x 21, 4 levels;
+// 83.7 us as launched here): features taken from per-XCD lists through atomic counters 119 us (some 1 200 dependent
+// atomics per counter, performed memory-side, cost more than the dispatches they replace), features dealt to the
+// resident wavefronts in fixed strides 88 us (no counters, but no balancing either).  Wavefronts that stay warm gain
+// nothing: the launch is bound by vector issue between its ends, and its ends by one wavefront's dependent chain.
+template <int SEGLEN, bool TALL>
+__global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
+    constexpr int WH_MAX = TALL ? 32 : 21;
+    constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;
+    constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;
+    constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
+    __shared__ uint32_t jlds[(4 * J_ROWS + 1) * LK_PITCH + 4];  // target region (+ a row for the staging's surplus rows, + slack: row reads are dword-granular)
+    __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: window + Scharr apron
+    const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
+    if (pt >= a.total) return;
+    lk_one_point<SEGLEN, TALL>(a, pt, threadIdx.x, jlds, ilds);
 }
 
 // The same tracking with two wavefronts per feature.  The template of a level (staging of the I region, Scharr patch,

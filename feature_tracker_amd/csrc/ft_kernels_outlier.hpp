@@ -18,7 +18,9 @@
 // LDS).  After every round one thread walks its models in index order exactly as a sequential loop would: a model with
 // more inliers than the best so far becomes the best and lowers the number of hypotheses still to be tried to the
 // smallest N with (1 - w^8)^N <= 0.001, w = its inlier ratio (the adaptive iteration count that the confidence argument
-// 0.999 of cv::findFundamentalMat stands for); models past that number are ignored.  The same workgroup then writes the
+// 0.999 of cv::findFundamentalMat stands for; OpenCV's own count falls with w^7, because its minimal sample has seven
+// points, and it switches to LMedS below 15 points: the search here is RANSAC on 8-point samples throughout); models past
+// that number are ignored.  The same workgroup then writes the
 // final mask and the batch results (positions, residuals, status) into the pinned host block.
 #pragma once
 #include "ft_kernels_lk.hpp"
@@ -35,7 +37,7 @@ struct OutlierArgs {
     float* out_xy;             // pinned host
     float* out_err;            // pinned host
     uint8_t* out_status;       // pinned host
-    int hypotheses;            // <= 256
+    int hypotheses;            // <= RO_MAX_HYP
     uint32_t seed;
     // completion flag (optional): the last workgroup to finish stores done_seq to done_flag (pinned host memory)
     unsigned* done_count;      // device, zero between launches
@@ -94,7 +96,7 @@ __device__ __forceinline__ bool ro_inlier(const double* F, float4 m, float thr2)
 constexpr int RO_HYP_PER_WG = 32;     // hypotheses per round (8 lanes each)
 constexpr int RO_SUB = 4;             // models whose inliers are counted together (a power of two)
 constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest is read from the global copy
-constexpr int RO_MAX_HYP = 256;       // upper bound of OutlierArgs::hypotheses
+constexpr int RO_MAX_HYP = 1024;      // upper bound of OutlierArgs::hypotheses
 constexpr int RO_CHUNK = 512;         // points per workgroup of a pair that is split into parts
 constexpr int RO_MAX_PARTS = 32;      // parts per pair at most (larger pairs get larger chunks)
 constexpr int RO_MAX_WGS = FT_MAX_BATCH;   // workgroups per launch when pairs are split: all of them fit the device at once
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
         if (t == 0) s_last = __hip_atomic_fetch_add(&gbar[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)parts - 1;
         __syncthreads();
         if (s_last) {
-            for (int i = t; i < RO_MAX_HYP; i += T) gcnt[i] = 0;
+            for (int i = t; i < min(RO_MAX_HYP, a.hypotheses + RO_HYP_PER_WG); i += T) gcnt[i] = 0;
             if (t < 2) gbar[t] = 0;
         }
     }
@@ -352,12 +354,15 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
     }
     if (a.done_flag) {
         // The results above went to pinned host memory, which no cache of the device holds: once a store is
-        // acknowledged (vmcnt) it has been performed.  A system-scope fence in every thread would also write back the
-        // whole L2 (12 us per launch, measured); one such fence before the flag store is kept, by one thread.
+        // acknowledged (vmcnt) it has been performed at the host.  The flag protocol rests on that property of the
+        // hardware, not on the language's memory model: the counter below is a relaxed atomic, and only the last
+        // workgroup issues a fence.  Release / acquire on the counter make every workgroup write back its L2 (measured:
+        // + 3.3 us per launch of 64 workgroups; a system-scope fence in every thread: + 12 us).  FT_DONE_FLAG=0 turns
+        // the flag off (every wait then goes through an event), for telling a stale result from another fault.
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __syncthreads();
         if (t == 0) {
-            const unsigned finished = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned finished = atomicAdd(a.done_count, 1u);
             if (finished == gridDim.x - 1) {   // every other workgroup's stores have been acknowledged
                 *a.done_count = 0;
                 __threadfence_system();

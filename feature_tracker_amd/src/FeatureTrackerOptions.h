@@ -36,7 +36,7 @@ struct FeatureTrackerOptions {
     // exists because the sampling is this build's own and cannot reproduce OpenCV's inlier sets point for point:
     // off leaves mask_out = the LK status (and the forward-backward check)
     bool reject_outliers = true;
-    int ransac_hypotheses = 256;
+    int ransac_hypotheses = 1000;
     // left -> right association of new features as TrackMsckfVio::stereoMatch does it (src/track/TrackMsckfVio.cpp:218-301):
     // guess from the stereo extrinsics instead of "same pixel" (the TODO at src/track/TrackKLT.cpp:290-295), then the
     // known-essential-matrix test.  Needs both cameras' extrinsics.

@@ -38,7 +38,7 @@ int TrackDescriptor::robust_match(const std::vector<KeyPoint>& pts0, const std::
     if (rc != FT_OK) return rc;
     good.resize((size_t)std::min(n_good, (int)good.size()));
     if (good.size() < 10) return FT_OK;   // not enough points for RANSAC: no matches at all (:276-277)
-    if (!ransac_pairs) {                  // :280-304 as written: see the header
+    if (!ransac_pairs) {                  // :280-304 as written rejects nothing (identical or affinely related sets): see the header
         matches = good;
         return FT_OK;
     }

@@ -7,11 +7,18 @@
 //  * the descriptor: cv::ORB::compute samples a table inside OpenCV; here it is the BRIEF-style descriptor of
 //    ft_compute_descriptors (same patch size, same keypoints dropped near the border);
 //  * equal Hamming distances: the lower train index comes first.
-// The RANSAC step of robust_match (src/track/TrackDescriptor.cpp:267-304) undistorts pts0 for BOTH point sets (:284-285),
-// so as written it compares a point set with itself and findFundamentalMat has nothing to reject: every match that passed
-// the ratio and symmetry tests is returned, provided there are at least ten (:276-277).  That is what this class does by
-// default.  set_ransac_on_matched_pairs(true) runs the outlier rejection on the matched pairs instead (the evident
-// intent), with the seeded RANSAC of ft_reject_outliers.
+// The RANSAC step of robust_match (src/track/TrackDescriptor.cpp:267-304) undistorts pts0 for BOTH point sets (:284-285):
+//  * temporal matches (id0 == id1): the two sets are identical, every pair fits any skew-symmetric matrix, and
+//    findFundamentalMat has nothing to reject;
+//  * left -> right matches (id0 != id1): the second set is pts0 under the other camera's model.  Without distortion the
+//    two sets differ by an affine map of the image plane, a three-parameter family of matrices fits every pair, and again
+//    nothing is rejected; with different distortion coefficients the map is no longer affine and the reference can drop
+//    matches - by how much the two lens models disagree at that pixel, not by the quality of the match.
+// This class returns every match that passed the ratio and symmetry tests, provided there are at least ten (:276-277):
+// the reference's outcome in the first two cases.  The third is a deviation (not reproduced: it is an artefact of the
+// slip at :285, and the seeded RANSAC here voids the degenerate systems that OpenCV's SVD resolves).
+// set_ransac_on_matched_pairs(true) runs the outlier rejection on the matched pairs instead (the evident intent), with
+// the seeded RANSAC of ft_reject_outliers.
 #pragma once
 #include <vector>
 

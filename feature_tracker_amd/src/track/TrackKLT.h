@@ -209,7 +209,7 @@ protected:
     float fb_thresh = 1.0f;
     bool speculative_detect = true;
     bool reject_outliers = true;
-    int ransac_hypotheses = 256;
+    int ransac_hypotheses = 1000;
     bool stereo_extrinsic_seed = false;
     double stereo_threshold = 3.0;
     double drop_fraction = 0.0;

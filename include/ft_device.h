@@ -49,8 +49,15 @@ extern "C" {
  * (FM_RANSAC, 1/max_focal, 0.999) + mask_klt & mask_ransac).  Model, error measure and threshold are OpenCV's; the
  * sampling is this library's own seeded scheme, because OpenCV's random sequence cannot be reproduced without it.
  * Hypotheses are tried in index order and, as in OpenCV, a better model lowers the number still to be tried (to the
- * smallest N with (1 - w^8)^N <= 0.001 for its inlier ratio w: confidence 0.999); ransac_hypotheses is the upper bound.
- * Jobs need calib_prev / calib_next. */
+ * smallest N with (1 - w^8)^N <= 0.001 for its inlier ratio w: confidence 0.999); ransac_hypotheses is the upper bound
+ * (OpenCV's is 1000 iterations).
+ * Where the search differs from OpenCV 3's (as its fundam.cpp is remembered; OpenCV is not available to check against):
+ * OpenCV draws 7-point minimal samples (up to three models each from the cubic in the null space, every one rank 2),
+ * lowers its iteration count with w^7, and for fewer than 15 points runs LMedS instead of RANSAC; here a sample is 8
+ * points, the model is the null vector of the 8x9 system (no rank-2 step), the count falls with w^8, and RANSAC runs
+ * from 8 points up.  The error measure, the threshold, the confidence and the iteration limit are OpenCV's.  What is
+ * tested is therefore not the inlier set but its quality: precision and recall against known outliers
+ * (tests/synth.py REJECTION_BARS).  Jobs need calib_prev / calib_next. */
 #define FT_LK_REJECT_OUTLIERS 512
 /* Do not compute the residual (err stays 0).  TrackKLT::perform_matching never reads the `error` vector it gets from
  * cv::calcOpticalFlowPyrLK (src/track/TrackKLT.cpp:399-402), so the tracker layer sets this; status is unaffected
@@ -77,7 +84,7 @@ typedef struct ft_lk_params {
     double min_eig;      /* OpenCV default 1e-4 */
     int flags;           /* FT_LK_* */
     float fb_thresh;     /* px; only with FT_LK_FORWARD_BACKWARD */
-    int ransac_hypotheses;    /* only with FT_LK_REJECT_OUTLIERS: models tried per job, 1..256 (0 = 256) */
+    int ransac_hypotheses;    /* only with FT_LK_REJECT_OUTLIERS: models tried per job at most, 1..1024 (0 = 1000) */
     unsigned ransac_seed;     /* only with FT_LK_REJECT_OUTLIERS: seed of the sample sequence */
     double stereo_threshold;  /* only for jobs with stereo_Rt: largest distance to the epipolar line, in pixels
                                  (src/track/TrackMsckfVio.h:217 -> 3); <= 0 switches the check off (seed only) */
@@ -184,7 +191,7 @@ int ft_lk_track_async(ft_ctx* ctx, int n_jobs, const ft_lk_job* jobs, const ft_l
  * 1/max_focal, 0.999) + "mask_klt && mask_ransac" of src/track/TrackKLT.cpp:405-424, for n_sets point sets in one
  * launch (all n points of a set enter the estimation, as in the reference; status only gates the output).  Same model
  * search as FT_LK_REJECT_OUTLIERS.  Fewer than 8 points, or no model with at least 8 inliers, clears the whole set.
- * hypotheses 1..256 (0 = 256).  Shares its staging with ft_lk_track: total points <= limits.max_points, and an
+ * hypotheses 1..1024 (0 = 1000).  Shares its staging with ft_lk_track: total points <= limits.max_points, and an
  * undelivered tracking batch is finished first. */
 int ft_reject_outliers(ft_ctx* ctx, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed);
 int ft_reject_outliers_async(ft_ctx* ctx, int n_sets, const ft_match_set* sets, int hypotheses, unsigned seed);

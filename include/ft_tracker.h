@@ -32,7 +32,7 @@ typedef struct ftk_options {
     float fb_thresh;
     int speculative_detect;
     int reject_outliers;    /* RANSAC on the fundamental matrix after LK, src/track/TrackKLT.cpp:405-424 -> on (see FT_LK_REJECT_OUTLIERS) */
-    int ransac_hypotheses;  /* -> 256 */
+    int ransac_hypotheses;  /* -> 1000 */
     int stereo_extrinsic_seed;  /* left -> right association seeded from the stereo extrinsics + known-E test,
                                    src/track/TrackMsckfVio.cpp:218-301 -> off ("same pixel", src/track/TrackKLT.cpp:290-295) */
     double stereo_threshold;    /* px, src/track/TrackMsckfVio.h:217 -> 3 */

@@ -770,8 +770,9 @@ inline bool is_inlier(const double (&F)[9], float x1, float y1, float x2, float 
 
 // Hypotheses to try before a sample of eight inliers has been drawn with probability 0.999 (the confidence handed to
 // cv::findFundamentalMat at src/track/TrackKLT.cpp:418), given the best model so far has `inliers` of n points: the
-// smallest N with (1 - w^8)^N <= 0.001, at most max_h.  OpenCV's RANSAC lowers its iteration count the same way
-// whenever it finds a better model; here the count comes from plain multiplications in a fixed order.
+// smallest N with (1 - w^8)^N <= 0.001, at most max_h.  OpenCV's RANSAC lowers its iteration count in the same manner
+// whenever it finds a better model, but with w^7 (its minimal sample has seven points; below 15 points it runs LMedS
+// instead); here samples have eight points and the count comes from plain multiplications in a fixed order.
 int hypotheses_needed(int inliers, int n, int max_h) {
     const double w = (double)inliers / (double)n;
     const double w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
@@ -793,7 +794,7 @@ extern "C" {
 int fto_reject_outliers(const float* prev_xy, const float* next_xy, uint8_t* status, int n, const double* calib8_prev,
                         const double* calib8_next, int hypotheses, uint32_t seed, double* F_out) {
     if (!prev_xy || !next_xy || !status || !calib8_prev || !calib8_next || n < 0) return -1;
-    if (hypotheses <= 0) hypotheses = 256;
+    if (hypotheses <= 0) hypotheses = 1000;   // OpenCV's iteration limit
     if (n < 8) {
         for (int i = 0; i < n; i++) status[i] = 0;
         return -1;

@@ -108,7 +108,7 @@ void fto_homography(const float* K4, const float* R_p_c, float* H);
  * variant with the same model, error measure and threshold:
  *   - both point sets are undistorted like TrackBase::undistort_point (src/track/TrackBase.h:289-332) and rounded to
  *     float, calib8 = fx, fy, cx, cy, k1, k2, p1, p2;
- *   - at most `hypotheses` models (0 = 256) are fitted in index order, model h from the 8 distinct pairs drawn by a
+ *   - at most `hypotheses` models (0 = 1000, the iteration limit of cv::findFundamentalMat) are fitted in index order, model h from the 8 distinct pairs drawn by a
  *     counter-based hash of (seed, h, draw number).  Whenever a model beats the best so far, the number of models still
  *     to be tried drops to the smallest N with (1 - w^8)^N <= 0.001, w = that model's inlier ratio: the adaptive
  *     iteration count behind the confidence argument 0.999 (OpenCV computes it with logarithms; here it comes from

@@ -412,6 +412,15 @@ def test_reject_outliers_split_pairs_equal_oracle(dev, sizes, n_out_frac, hyp):
                 assert np.array_equal(g, w_)
 
 
+@pytest.mark.parametrize("n,share", sorted(synth.REJECTION_BARS))
+def test_reject_outliers_precision_and_recall_against_ground_truth(dev, n, share):
+    """The device's masks against the known random matches, at the same bars as the CPU checker's (tests/synth.py)."""
+    p_bar, r_bar = synth.REJECTION_BARS[(n, share)]
+    with _ctx(dev, 64, 64, max_points=n + 16) as ctx:
+        p, r = synth.rejection_scores(lambda a, b, c, seed: ctx.reject_outliers([dict(prev_xy=a, next_xy=b, calib_prev=c)], hypotheses=0, seed=seed)[0], n, share)
+    assert p >= p_bar and r >= r_bar, (p, r)
+
+
 def test_reject_outliers_more_parts_than_the_device_holds(dev, monkeypatch):
     """A launch whose split pairs would need more than 256 workgroups runs one workgroup per pair instead, and
     FT_RO_SPLIT=0 does so always: same masks either way."""

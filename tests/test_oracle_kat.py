@@ -280,6 +280,17 @@ def test_reject_outliers_separates_random_matches(calib8, t):
         assert np.median(r) < 2e-3
 
 
+@pytest.mark.parametrize("n,share", sorted(__import__("synth").REJECTION_BARS))
+def test_reject_outliers_precision_and_recall_against_ground_truth(n, share):
+    """The claim that the build's own RANSAC does what the reference's findFundamentalMat step is for, as numbers: with
+    the reference's threshold (1 / max_focal) and OpenCV's iteration limit, precision and recall of the final mask
+    against the known random matches, for a dozen, 150 and 2000 points."""
+    import synth
+    p_bar, r_bar = synth.REJECTION_BARS[(n, share)]
+    p, r = synth.rejection_scores(lambda a, b, c, seed: O.reject_outliers(a, b, np.ones(len(a), np.uint8), c, hypotheses=0, seed=seed)[0], n, share)
+    assert p >= p_bar and r >= r_bar, (p, r)
+
+
 def test_reject_outliers_is_deterministic_and_keeps_lost_points_lost():
     import synth
     calib8 = (460.0, 458.0, 376.0, 240.0, -0.1, 0.01, 0.0, 0.0)
