@@ -106,11 +106,15 @@ constexpr unsigned RO_SPIN_LIMIT = 1u << 20;   // barrier polls before a part gi
 // k-th barrier of the launch is passed when parts * (k + 1) arrivals have been counted.  All parts of a launch are
 // resident at once (the host never launches more split workgroups than the device holds), so every arrival comes;
 // the poll count is bounded all the same, and a part that gives up reports it instead of hanging the queue.
+// Everything the parts share (the inlier totals and this counter) is read and written with device-scope atomic
+// operations only, which are performed at the memory side, past the per-XCD caches; the callers' additions have
+// returned their old values before the arrival is counted.  So no cache has to be written back or invalidated here
+// (release / acquire on the counter cost about 2 us per barrier, a tenth of the kernel).
 __device__ inline bool ro_pair_barrier(unsigned* bar, unsigned target) {
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned spins = 0; spins < RO_SPIN_LIMIT; spins++) {
-        if (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        __builtin_amdgcn_s_sleep(4);
+        if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(2);
     }
     return false;
 }
@@ -305,7 +309,10 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
             __syncthreads();
             if (parts > 1) {
                 // own counts to the pair's totals, barrier among the parts, totals back (every part reads the same)
-                if (t < RO_SUB && cnt[q0 + t]) atomicAdd(&gcnt[h0 + q0 + t], cnt[q0 + t]);
+                if (t < RO_SUB && cnt[q0 + t]) {
+                    const int before = atomicAdd(&gcnt[h0 + q0 + t], cnt[q0 + t]);
+                    asm volatile("" ::"v"(before));   // the addition has been performed once its old value is here
+                }
                 __syncthreads();
                 if (t == 0) {
                     barriers++;
@@ -337,11 +344,11 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
         // the last part of the pair to get here leaves the pair's counters at zero for the next launch (every part has
         // passed its last barrier and read its last totals by then)
         __shared__ unsigned s_last;
-        if (t == 0) s_last = __hip_atomic_fetch_add(&gbar[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)parts - 1;
+        if (t == 0) s_last = __hip_atomic_fetch_add(&gbar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)parts - 1;
         __syncthreads();
-        if (s_last) {
-            for (int i = t; i < min(RO_MAX_HYP, a.hypotheses + RO_HYP_PER_WG); i += T) gcnt[i] = 0;
-            if (t < 2) gbar[t] = 0;
+        if (s_last) {   // (atomic stores, like every other access to these words)
+            for (int i = t; i < min(RO_MAX_HYP, a.hypotheses + RO_HYP_PER_WG); i += T) __hip_atomic_store(&gcnt[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < 2) __hip_atomic_store(&gbar[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     for (int i = t; i < own; i += T) {

@@ -58,7 +58,7 @@ class Occupancy:
 
 class StereoTrackerRef:
     def __init__(self, num_features=150, fast_threshold=20, grid_x=5, grid_y=5, min_px_dist=10, win=15, levels=3, calib=None,
-                 hypotheses=256, reject_outliers=True):
+                 hypotheses=1000, reject_outliers=True):
         self.num_features, self.threshold, self.grid_x, self.grid_y, self.min_px_dist = num_features, fast_threshold, grid_x, grid_y, min_px_dist
         self.win, self.levels, self.calib, self.hypotheses, self.reject = win, levels, calib, hypotheses, reject_outliers
         self.currid = 1                       # TrackBase(numfeats, numaruco = 0): currid = numaruco + 1 (src/track/TrackBase.h:86-89)

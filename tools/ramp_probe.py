@@ -14,6 +14,13 @@ time.sleep(0.5)
 f = bench.Feeder(tracker, wl, seqs, dev_frames, 0, 0, 0, False)
 f.run(0, 1)
 torch.cuda.synchronize()
+if os.environ.get('RAMP_PREHEAT'):   # keep the device busy for a while right before the first step: clock ramp or host-side warm-up?
+    a = torch.randn(4096, 4096, device=dev)
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < float(os.environ['RAMP_PREHEAT']):
+        for _ in range(10):
+            a = (a @ a).clamp_(-1, 1)
+        torch.cuda.synchronize()
 t0 = time.perf_counter(); marks=[]
 for i in range(1, K+1):
     f.feed(i); marks.append(time.perf_counter()-t0)
