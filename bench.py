@@ -7,7 +7,7 @@ rejection, host bookkeeping and feature-database update.  The frames are synthet
 `value` they are resident in HBM before the timed region starts; the same run also reports the rate with the frames
 handed over as host pointers (PCIe inside the clock) and the rate without the outlier rejection.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg5] [--scaling strong|weak]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg4_win15|cfg2|cfg3|cfg5] [--scaling strong|weak]
 
 N > 1: one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) the process is one of those ranks and
 refuses to run if WORLD_SIZE differs from --gpus; started plain, it launches the N ranks itself as a child
@@ -44,6 +44,10 @@ WORKLOADS = {
     # configs[3]: 64 independent 752x480 streams batched
     "cfg4": dict(desc="64 x 752x480 streams, 150 features each, maxLevel 3, win 21, gyro seed, batched launches",
                  streams=64, w=752, h=480, opts=dict(num_pts=150, win_size=21, pyr_levels=3, use_gyro_seed=1), seq={}),
+    # configs[3] with the reference's own window (src/track/TrackKLT.h:122): the 15x15 form of the tracking kernel (4-pixel
+    # segments, 60 of 64 lanes)
+    "cfg4_win15": dict(desc="64 x 752x480 streams, 150 features each, maxLevel 3, win 15 (the reference's window), gyro seed, batched launches",
+                       streams=64, w=752, h=480, opts=dict(num_pts=150, win_size=15, pyr_levels=3, use_gyro_seed=1), seq={}),
     # configs[4]: 3840x2160, 10k features, 5 levels, replenishment forced every frame (5 % of the tracks dropped per frame)
     "cfg5": dict(desc="1 x 3840x2160 stream per GPU, 10k features, maxLevel 5, win 21, grid 26x15, 5 % of the tracks dropped "
                       "every frame so that the detector replenishes on every frame",
@@ -53,26 +57,32 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
-# HBM bytes per unit of work from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
-# doubled as gfx950 requires; profiles/*_pmc_hbm_traffic.json): (bytes, unit); None where no pass has been made
-_T_SRC = "profiles/r2_o_pmc_hbm_traffic.json"
-MEASURED_TRAFFIC = {
-    ("cfg4", "lk_track"): (6590.5 + 17.6, "point", _T_SRC),
-    ("cfg4", "pyramid"): (491906.6 + 489636.8, "frame", _T_SRC),
-    ("cfg4", "fast_grid"): (374039.9 + 16777.2 + 8272.0 + 3343.7, "frame", _T_SRC),    # detector + top-k
-    ("cfg4", "outlier_rejection"): (104.3 + 13.7, "point", _T_SRC),
-}
+# HBM bytes and vector-ALU instructions per unit of work (camera frame or tracked point), from rocprofv3 counter passes
+# over this benchmark: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as gfx950 requires
+# (tools/profile_r3.sh, tools/pmc_per_unit.py).  They are not measured in the run that prints them: the line carries the
+# per-unit figures times that run's unit counts, and names this file as their source.  These kernels are bound by
+# vector-instruction issue, not by HBM: one SIMD issues one wave instruction per 4 cycles, so the device peak is
+# CUs * 4 SIMDs * clock / 4.
+PMC_FILE = os.path.join("profiles", "pmc_per_unit.json")
 
-# Vector-ALU instructions per wavefront ("wave instructions") per unit of work, from a rocprofv3 SQ_INSTS_VALU / SQ_WAVES
-# pass over this workload (profiles/*_pmc_insts.txt).  These kernels are bound by vector-instruction issue, not by HBM:
-# one SIMD issues one wave instruction per 4 cycles, so the device peak is CUs * 4 SIMDs * clock / 4.
-_V_SRC = "profiles/r2_o_pmc_insts.txt"
-MEASURED_VALU = {
-    ("cfg4", "lk_track"): (3442.3, "point", _V_SRC),                                   # one wave per point
-    ("cfg4", "pyramid"): ((160.6 * 23040 + 2 * 144.7 * 4096) / 64.0, "frame", _V_SRC),
-    ("cfg4", "fast_grid"): ((863.5 * 13312 + 253.2 * 1600) / 64.0, "frame", _V_SRC),
-    ("cfg4", "outlier_rejection"): (2929.5 * 256 / 8872.0, "point", _V_SRC),           # 256 waves per launch of 8872 points
-}
+
+def load_pmc():
+    """{(workload, kind): (value, unit, source)} for traffic and for vector instructions; empty without the file."""
+    traffic, valu = {}, {}
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return traffic, valu
+    for wl, e in doc.get("workloads", {}).items():
+        for kind, (v, unit) in e.get("traffic", {}).items():
+            traffic[(wl, kind)] = (v, unit, PMC_FILE)
+        for kind, (v, unit) in e.get("valu", {}).items():
+            valu[(wl, kind)] = (v, unit, PMC_FILE)
+    return traffic, valu
+
+
+MEASURED_TRAFFIC, MEASURED_VALU = load_pmc()
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0
 
 
@@ -552,9 +562,7 @@ def main():
             # streams, the 1280x720 forward-backward configuration and the 3840x2160 one
             K2, W2 = min(K, 20), min(W, 10)
             sides = {}
-            wl15 = dict(wl, desc=wl["desc"].replace("win 21", "win 15 (the reference's window, src/track/TrackKLT.h:122)"),
-                        opts=dict(wl["opts"], win_size=15))
-            sides["cfg4_win15"] = B.side_workload("cfg4_win15", wl15, K2, W2, seqs, dev_frames,
+            sides["cfg4_win15"] = B.side_workload("cfg4_win15", WORKLOADS["cfg4_win15"], K2, W2, seqs, dev_frames,   # same streams, same frames
                                                   cpu_budget_s=0.0 if args.no_cpu_baseline else 6.0)
             for name in ("cfg3", "cfg5"):
                 sides[name] = B.side_workload(name, WORKLOADS[name], K2, W2)
