@@ -288,7 +288,8 @@ int sync_and_deliver(ft_ctx* c) {
 
 // counts[j]: points of pair j.  Pairs of more than RO_CHUNK points are split into parts, one workgroup each, as long as
 // the launch then has at most RO_MAX_WGS workgroups: the parts of a pair wait for each other inside the kernel, so all
-// of them must be resident at once (256 threads and the hypothesis phase's registers: two workgroups per compute unit).
+// of them must be resident at once (256 threads and the hypothesis phase's registers: two workgroups per compute unit;
+// RO_MAX_WGS leaves room for four such launches at a time).
 void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, const int* counts) {
     EventPair ep;
     prof_begin(c, 3, ep);

@@ -99,7 +99,9 @@ constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest
 constexpr int RO_MAX_HYP = 1024;      // upper bound of OutlierArgs::hypotheses
 constexpr int RO_CHUNK = 512;         // points per workgroup of a pair that is split into parts
 constexpr int RO_MAX_PARTS = 32;      // parts per pair at most (larger pairs get larger chunks)
-constexpr int RO_MAX_WGS = FT_MAX_BATCH;   // workgroups per launch when pairs are split: all of them fit the device at once
+constexpr int RO_MAX_WGS = 128;      // workgroups per launch when pairs are split.  The parts of a pair wait for each other, so
+                                     // every workgroup of such a launch must become resident while others spin: the device holds 512
+                                     // of them (two per compute unit), which leaves room for the launches of four contexts at once
 constexpr unsigned RO_SPIN_LIMIT = 1u << 20;   // barrier polls before a part gives up (a fraction of a second)
 
 // Barrier among the `parts` workgroups of one pair, called by one thread per workgroup after a workgroup barrier.  The

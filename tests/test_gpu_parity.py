@@ -422,25 +422,25 @@ def test_reject_outliers_precision_and_recall_against_ground_truth(dev, n, share
 
 
 def test_reject_outliers_more_parts_than_the_device_holds(dev, monkeypatch):
-    """A launch whose split pairs would need more than 256 workgroups runs one workgroup per pair instead, and
+    """A launch whose split pairs would need more than 128 workgroups runs one workgroup per pair instead, and
     FT_RO_SPLIT=0 does so always: same masks either way."""
     calib = CALIBS[1]
     sets, want = [], []
-    for k in range(90):
+    for k in range(50):
         n = 1100 if k % 2 == 0 else 30
         prev, nxt, _ = synth.two_view_matches(n, n // 5, calib, seed=300 + k)
         sets.append(dict(prev_xy=prev, next_xy=nxt, calib_prev=calib))
     want = [O.reject_outliers(q["prev_xy"], q["next_xy"], np.ones(len(q["prev_xy"]), np.uint8), calib, calib, hypotheses=32, seed=1)[0] for q in sets[:6]]
     with _ctx(dev, 64, 64, max_points=60000) as ctx:
-        got = ctx.reject_outliers(sets, hypotheses=32, seed=1)               # 45 * 3 + 45 = 180 workgroups: split
+        got = ctx.reject_outliers(sets, hypotheses=32, seed=1)               # 25 * 3 + 25 = 100 workgroups: split
         got_few = ctx.reject_outliers(sets[:6], hypotheses=32, seed=1)
     monkeypatch.setenv("FT_RO_SPLIT", "0")
     with _ctx(dev, 64, 64, max_points=60000) as ctx:
         got_one = ctx.reject_outliers(sets, hypotheses=32, seed=1)
-    big = [dict(prev_xy=np.tile(q["prev_xy"], (3, 1)), next_xy=np.tile(q["next_xy"], (3, 1)), calib_prev=calib) for q in sets[:80:2]]
+    big = [dict(prev_xy=np.tile(q["prev_xy"], (3, 1)), next_xy=np.tile(q["next_xy"], (3, 1)), calib_prev=calib) for q in sets[:40:2]]
     monkeypatch.delenv("FT_RO_SPLIT")
-    with _ctx(dev, 64, 64, max_points=140000) as ctx:
-        got_big = ctx.reject_outliers(big, hypotheses=32, seed=1)            # 40 * 7 = 280 workgroups: not split
+    with _ctx(dev, 64, 64, max_points=70000) as ctx:
+        got_big = ctx.reject_outliers(big, hypotheses=32, seed=1)            # 20 * 7 = 140 workgroups: not split
     for i in range(6):
         assert np.array_equal(got[i], want[i]) and np.array_equal(got_few[i], want[i])
     for a, b in zip(got, got_one):
