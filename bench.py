@@ -441,6 +441,13 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
 
+    # Hardware queues of this process (HIP reads the variable when it initialises, so this comes before torch): the batch
+    # layer gives every stream group a queue of its own and runs four groups instead of three when the process has eight
+    # hardware queues (HIP's default is 4; measured + 4 %: 73 against 70.5 M features/s).  FT_BENCH_KEEP_HW_QUEUES=1
+    # leaves the environment as it is.
+    if not os.environ.get("FT_BENCH_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
     # ---- the rank layout, before anything touches the GPU ----
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -538,7 +545,8 @@ def main():
                        "width": w, "height": h, "features_per_stream": wl["opts"]["num_pts"], "window": win, "max_level": lv,
                        "frames_in_hbm": not args.host_frames, "outlier_rejection": not args.no_reject_outliers,
                        "forward_backward": bool(wl["opts"].get("forward_backward")), "drop_fraction": wl["opts"].get("drop_fraction", 0.0),
-                       "scene": wl.get("seq", {}).get("scene", "shapes")},
+                       "scene": wl.get("seq", {}).get("scene", "shapes"),
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)},
             "clock": "barrier + synchronize, first feed ... flush() returned (all results of the K steps on the host, databases "
                      "written), slowest rank; the closing synchronize + barrier comes after it",
             "ms_per_step_incl_closing_sync": 1e3 * dt_closed_max / K,
