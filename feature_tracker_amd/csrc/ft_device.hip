@@ -88,6 +88,7 @@ struct ft_ctx {
     int* ro_gcnt_dev = nullptr;          // outlier rejection, pairs split over workgroups: inlier totals [pair][RO_MAX_HYP]
     unsigned* ro_gbar_dev = nullptr;     // ... and per pair {barrier arrivals, finished parts}; both zero between launches
     bool ro_split = true;                // FT_RO_SPLIT=0: one workgroup per pair whatever its size
+    unsigned ro_spin_limit = RO_SPIN_LIMIT;   // FT_RO_SPIN_LIMIT: barrier polls before a part of a split pair gives up (tests set it to 1)
     bool use_done_flag = true;           // FT_DONE_FLAG=0: every fence records an event; the kernel's completion flag is not used
     uint32_t done_seq = 0;               // last sequence number handed to a launch
     uint32_t tail_flag_seq = 0;          // != 0: the newest work on the queue is the launch that stores this number
@@ -295,7 +296,7 @@ void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, const int* counts) {
     prof_begin(c, 3, ep);
     const uint32_t seq = ++c->done_seq ? c->done_seq : ++c->done_seq;   // never 0
     o.done_count = c->done_count_dev; o.done_flag = c->use_done_flag ? c->done_flag_dev : nullptr; o.done_seq = seq;
-    o.gcnt = c->ro_gcnt_dev; o.gbar = c->ro_gbar_dev; o.error_flag = c->done_flag_dev + FT_RO_ERROR_WORD;
+    o.gcnt = c->ro_gcnt_dev; o.gbar = c->ro_gbar_dev; o.error_flag = c->done_flag_dev + FT_RO_ERROR_WORD; o.spin_limit = c->ro_spin_limit;
     int parts[FT_MAX_BATCH], wgs = 0, max_points = 0;
     for (int j = 0; j < n_jobs; j++) {
         parts[j] = c->ro_split ? std::min(std::max((counts[j] + RO_CHUNK - 1) / RO_CHUNK, 1), RO_MAX_PARTS) : 1;
@@ -503,6 +504,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     if (hipMemset(c->ro_gbar_dev, 0, sizeof(unsigned) * 2 * FT_MAX_BATCH) != hipSuccess) return fail(FT_E_HIP);
     if (const char* e = getenv("FT_RO_SPLIT")) c->ro_split = atoi(e) != 0;
     if (const char* e = getenv("FT_DONE_FLAG")) c->use_done_flag = atoi(e) != 0;
+    if (const char* e = getenv("FT_RO_SPIN_LIMIT")) c->ro_spin_limit = (unsigned)std::max(1, atoi(e));
     if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->done_flag_host = (unsigned*)p;
     memset(c->done_flag_host, 0, 256);

@@ -48,6 +48,7 @@ struct OutlierArgs {
     int* gcnt;
     unsigned* gbar;
     unsigned* error_flag;
+    unsigned spin_limit;       // barrier polls before a part gives up
     // workgroup -> pair | part << 16 | parts << 24
     uint32_t wg_map[FT_MAX_BATCH];
 };
@@ -102,7 +103,7 @@ constexpr int RO_MAX_PARTS = 32;      // parts per pair at most (larger pairs ge
 constexpr int RO_MAX_WGS = 128;      // workgroups per launch when pairs are split.  The parts of a pair wait for each other, so
                                      // every workgroup of such a launch must become resident while others spin: the device holds 512
                                      // of them (two per compute unit), which leaves room for the launches of four contexts at once
-constexpr unsigned RO_SPIN_LIMIT = 1u << 20;   // barrier polls before a part gives up (a fraction of a second)
+constexpr unsigned RO_SPIN_LIMIT = 1u << 20;   // barrier polls before a part gives up (a fraction of a second); OutlierArgs::spin_limit
 
 // Barrier among the `parts` workgroups of one pair, called by one thread per workgroup after a workgroup barrier.  The
 // k-th barrier of the launch is passed when parts * (k + 1) arrivals have been counted.  All parts of a launch are
@@ -112,9 +113,9 @@ constexpr unsigned RO_SPIN_LIMIT = 1u << 20;   // barrier polls before a part gi
 // operations only, which are performed at the memory side, past the per-XCD caches; the callers' additions have
 // returned their old values before the arrival is counted.  So no cache has to be written back or invalidated here
 // (release / acquire on the counter cost about 2 us per barrier, a tenth of the kernel).
-__device__ inline bool ro_pair_barrier(unsigned* bar, unsigned target) {
+__device__ inline bool ro_pair_barrier(unsigned* bar, unsigned target, unsigned spin_limit) {
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (unsigned spins = 0; spins < RO_SPIN_LIMIT; spins++) {
+    for (unsigned spins = 0; spins < spin_limit; spins++) {
         if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
         __builtin_amdgcn_s_sleep(2);
     }
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
                 __syncthreads();
                 if (t == 0) {
                     barriers++;
-                    if (!ro_pair_barrier(gbar, (unsigned)parts * barriers)) s_abort = 1;
+                    if (!ro_pair_barrier(gbar, (unsigned)parts * barriers, a.spin_limit)) s_abort = 1;
                     for (int q = q0; q < q0 + RO_SUB; q++) cnt[q] = __hip_atomic_load(&gcnt[h0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }

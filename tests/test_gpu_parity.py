@@ -449,6 +449,34 @@ def test_reject_outliers_more_parts_than_the_device_holds(dev, monkeypatch):
     assert np.array_equal(got_big[0], w0)
 
 
+def test_reject_outliers_barrier_that_gives_up_is_an_error_not_a_hang(dev, monkeypatch):
+    """The workgroups of a split pair wait for each other with a bounded number of polls.  With the bound at one poll
+    some workgroup gives up: the call returns an error (no mask is delivered as if it were a result), the queue is not
+    hung, and a context with the normal bound then gets the checker's masks again."""
+    calib = CALIBS[0]
+    sets = []
+    for k in range(6):
+        prev, nxt, _ = synth.two_view_matches(3000, 900, calib, seed=500 + k)
+        sets.append(dict(prev_xy=prev, next_xy=nxt, calib_prev=calib))
+    monkeypatch.setenv("FT_RO_SPIN_LIMIT", "1")
+    with _ctx(dev, 64, 64, max_points=20000) as ctx:
+        failed = 0
+        for _ in range(5):
+            try:
+                ctx.reject_outliers(sets, hypotheses=64, seed=3)
+            except dev.FtError as e:
+                failed += 1
+                assert e.code == -3 and "barrier" in str(e)
+        assert failed >= 1
+        small = ctx.reject_outliers([dict(prev_xy=sets[0]["prev_xy"][:200], next_xy=sets[0]["next_xy"][:200], calib_prev=calib)], hypotheses=64, seed=3)[0]
+        assert np.array_equal(small, O.reject_outliers(sets[0]["prev_xy"][:200], sets[0]["next_xy"][:200], np.ones(200, np.uint8), calib, hypotheses=64, seed=3)[0])
+    monkeypatch.delenv("FT_RO_SPIN_LIMIT")
+    with _ctx(dev, 64, 64, max_points=20000) as ctx:
+        got = ctx.reject_outliers(sets, hypotheses=64, seed=3)
+    for q, g in zip(sets, got):
+        assert np.array_equal(g, O.reject_outliers(q["prev_xy"], q["next_xy"], np.ones(3000, np.uint8), calib, hypotheses=64, seed=3)[0])
+
+
 def test_reject_outliers_degenerate_sets(dev):
     calib = CALIBS[0]
     prev, nxt, _ = synth.two_view_matches(100, 0, calib, seed=5)
