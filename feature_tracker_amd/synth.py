@@ -100,3 +100,14 @@ class Sequence:
         rate = amp * (wr * fps) * np.cos(wr * fps * (self.imu_t - 1000.0) + pr)
         self.gyro = np.stack([np.zeros_like(rate), np.zeros_like(rate), rate], axis=1)
         self.accel = np.tile([0.0, 0.0, 9.81], (len(rate), 1))
+
+    def true_position(self, xy, frame_from, frame_to):
+        """Where the scene points seen at pixels xy (n, 2) in frame `frame_from` appear in frame `frame_to`: frame i
+        shows the canvas point c_i + R(theta_i) (p - h) at pixel p, h = the frame centre."""
+        h = np.array([(self.w - 1) * 0.5, (self.h - 1) * 0.5])
+
+        def rot(t):
+            return np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+
+        on_canvas = self.center[frame_from] + (np.asarray(xy, dtype=np.float64) - h) @ rot(self.theta[frame_from]).T
+        return h + (on_canvas - self.center[frame_to]) @ rot(self.theta[frame_to])     # R(-theta) = R(theta)^T

@@ -72,6 +72,17 @@ def test_full_size_configurations_match_cpu_checker(name, w, h, opts, min_pts):
             assert len(np.setdiff1d(b[0][1], a[0][1])) >= 0.03 * min_pts
 
 
+@pytest.mark.parametrize("opts", [dict(win_size=15), dict(win_size=21, use_gyro_seed=1)])
+def test_tracks_follow_the_true_motion_on_the_device(opts):
+    """Absolute accuracy of the product path against the motion the synthetic sequence was made with (same bars as the
+    CPU checker's run in tests/test_tracker_cpu.py)."""
+    from test_tracker_cpu import check_tracks_follow_the_true_motion
+    seq = synth.Sequence(752, 480, 20, stream_id=0)
+    b = tracker.BatchTracker(1, seq.w, seq.h, **opts)
+    hist = [(tr, at, pts[0][0].copy(), pts[0][1].copy()) for tr, at, pts in _feed_all(b, [seq], 20)]
+    check_tracks_follow_the_true_motion(seq, hist)
+
+
 def test_batch_tracker_with_outlier_rejection_matches_cpu_checker():
     """Scenes with independently moving patches; the rejection kernel must drop exactly the features the CPU
     checker drops (same seeded hypotheses, same arithmetic), frame after frame."""
