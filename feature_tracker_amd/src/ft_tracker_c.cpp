@@ -120,16 +120,22 @@ struct ftk_group {
     // feature-database writers: nothing in tracking depends on the database, so its updates run on their own threads,
     // off the driver's critical path.  Writer w applies the streams s with s % N_WRITERS == w of every frame set, in
     // frame order, so one stream's observations are always applied in order by one thread.
-    static constexpr int N_WRITERS = 2;
+    static constexpr int MAX_WRITERS = 4;
+    // writer threads per group (FT_DB_WRITERS overrides it, 1..4)
+    const int N_WRITERS = [] {
+        const char* e = getenv("FT_DB_WRITERS");
+        const int v = e ? atoi(e) : 2;
+        return v < 1 ? 1 : (v > MAX_WRITERS ? MAX_WRITERS : v);
+    }();
     struct DbJob {
         std::vector<TrackKLT::MonoPlan> payload;
         std::atomic<int> remaining{0};
-        int parts = N_WRITERS;      // threads that share the payload (streams s with s % parts == p go to thread p)
+        int parts = 2;              // threads that share the payload (streams s with s % parts == p go to thread p)
     };
-    std::thread writers[N_WRITERS];
+    std::thread writers[MAX_WRITERS];
     std::mutex wm;
     std::condition_variable wcv;
-    std::deque<DbJob*> wq[N_WRITERS];
+    std::deque<DbJob*> wq[MAX_WRITERS];
     std::deque<std::unique_ptr<DbJob>> wfree;
     std::vector<std::unique_ptr<DbJob>> wbusy;   // jobs in flight (owned here, referenced by the queues)
     long w_posted = 0;
