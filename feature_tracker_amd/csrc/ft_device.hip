@@ -1064,13 +1064,8 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     prof_begin(c, 2, ep);
     const int tiles = fast_tiles_x(w) * fast_tiles_y(h);
     hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(64), 0, enq(c), c->arena, L, G, c->cand, c->cand_count);
-    // the ranking kernel reports its own completion like the rejection kernel: a fence taken right after this call is
-    // then waited for by polling pinned memory, not through an event
-    const uint32_t flag_seq = ++c->done_seq ? c->done_seq : ++c->done_seq;   // never 0
-    hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells,
-                       c->done_count_dev, c->use_done_flag ? c->done_flag_dev : (unsigned*)nullptr, (unsigned)flag_seq);
+    hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
     prof_end(c, ep);
-    if (!(c->profile & 1) && c->use_done_flag) c->tail_flag_seq = flag_seq;
     FT_HIP(c, hipGetLastError());
     // cand is indexed [image*cells + cell][cand_cap], the keypoints [image*cells + cell][per_cell]
     PendingFast& F = c->fast_pending[ring];

@@ -326,57 +326,42 @@ __device__ __forceinline__ uint32_t fast_wave_max(uint32_t v) {
 constexpr int FT_TOPK_REGS = 4;
 __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32_t* __restrict__ cand, int* __restrict__ cand_count,
                                                        ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count,
-                                                       int total_cells, unsigned* __restrict__ done_count, unsigned* done_flag, unsigned done_seq) {
+                                                       int total_cells) {
     const int lane = threadIdx.x & 63;
     const int gcell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gcell < total_cells) {                 // uniform for the wave
-        const int cell = gcell % (G.ct_cols * G.ct_rows);
-        const int survivors = cand_count[(size_t)gcell * FAST_COUNT_STRIDE];
-        const int n = min(survivors, G.cand_cap);
-        const uint32_t* c = cand + (uint64_t)gcell * G.cand_cap;
-        const int keep = min(n, G.per_cell);
-        const int cell_x = (cell % G.ct_cols) * G.size_x, cell_y = (cell / G.ct_cols) * G.size_y;
-        uint32_t key[FT_TOPK_REGS];
+    if (gcell >= total_cells) return;          // uniform for the wave
+    const int cell = gcell % (G.ct_cols * G.ct_rows);
+    const int survivors = cand_count[(size_t)gcell * FAST_COUNT_STRIDE];
+    const int n = min(survivors, G.cand_cap);
+    const uint32_t* c = cand + (uint64_t)gcell * G.cand_cap;
+    const int keep = min(n, G.per_cell);
+    const int cell_x = (cell % G.ct_cols) * G.size_x, cell_y = (cell / G.ct_cols) * G.size_y;
+    uint32_t key[FT_TOPK_REGS];
 #pragma unroll
-        for (int k = 0; k < FT_TOPK_REGS; k++) key[k] = (lane + 64 * k < n) ? c[lane + 64 * k] : 0u;
-        uint32_t bound = 0xffffffffu;
-        for (int r = 0; r < keep; r++) {
-            uint32_t best = 0;
+    for (int k = 0; k < FT_TOPK_REGS; k++) key[k] = (lane + 64 * k < n) ? c[lane + 64 * k] : 0u;
+    uint32_t bound = 0xffffffffu;
+    for (int r = 0; r < keep; r++) {
+        uint32_t best = 0;
 #pragma unroll
-            for (int k = 0; k < FT_TOPK_REGS; k++) best = max(best, key[k] < bound ? key[k] : 0u);
-            for (int i = lane + 64 * FT_TOPK_REGS; i < n; i += 64) {
-                const uint32_t k = c[i];
-                if (k < bound && k > best) best = k;
-            }
-            best = fast_wave_max(best);
-            if (lane == 0) {
-                ft_keypoint kp;
-                kp.x = (float)(cell_x + 4095 - (int)(best & 0xfff));
-                kp.y = (float)(cell_y + 4095 - (int)((best >> 12) & 0xfff));
-                kp.response = (float)(best >> 24);
-                out[(uint64_t)gcell * G.per_cell + r] = kp;
-            }
-            bound = best;
+        for (int k = 0; k < FT_TOPK_REGS; k++) best = max(best, key[k] < bound ? key[k] : 0u);
+        for (int i = lane + 64 * FT_TOPK_REGS; i < n; i += 64) {
+            const uint32_t k = c[i];
+            if (k < bound && k > best) best = k;
         }
-        if (lane == 0) {   // after the wave's read of the counter above (program order within the wave)
-            out_count[gcell] = keep;
-            surv_count[gcell] = survivors;
-            cand_count[(size_t)gcell * FAST_COUNT_STRIDE] = 0;
+        best = fast_wave_max(best);
+        if (lane == 0) {
+            ft_keypoint kp;
+            kp.x = (float)(cell_x + 4095 - (int)(best & 0xfff));
+            kp.y = (float)(cell_y + 4095 - (int)((best >> 12) & 0xfff));
+            kp.response = (float)(best >> 24);
+            out[(uint64_t)gcell * G.per_cell + r] = kp;
         }
+        bound = best;
     }
-    if (done_flag) {
-        // Completion flag, as in ransac_kernel: the results went to pinned host memory, where a store has been performed
-        // once it is acknowledged; the last workgroup to get here stores the launch's sequence number for the host to poll.
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned finished = atomicAdd(done_count, 1u);
-            if (finished == gridDim.x - 1) {
-                *done_count = 0;
-                __threadfence_system();
-                *reinterpret_cast<volatile unsigned*>(done_flag) = done_seq;
-            }
-        }
+    if (lane == 0) {   // after the wave's read of the counter above (program order within the wave)
+        out_count[gcell] = keep;
+        surv_count[gcell] = survivors;
+        cand_count[(size_t)gcell * FAST_COUNT_STRIDE] = 0;
     }
 }
 

@@ -121,12 +121,16 @@ struct ftk_group {
     // off the driver's critical path.  Writer w applies the streams s with s % N_WRITERS == w of every frame set, in
     // frame order, so one stream's observations are always applied in order by one thread.
     static constexpr int MAX_WRITERS = 4;
-    // writer threads per group (FT_DB_WRITERS overrides it, 1..4)
-    const int N_WRITERS = [] {
+    // Writer threads of this group: two, or four for streams of a thousand features and more (their databases have four
+    // shards, and two writers fall behind a 10 000-feature stream: 0.3 ms per frame's observations, wake-up included,
+    // against a frame every 0.26 ms; the backlog then waits for the caller at the end of a burst).  FT_DB_WRITERS (1..4)
+    // overrides it.  Set before start().
+    int N_WRITERS = 2;
+    void choose_writers(int features_per_stream) {
         const char* e = getenv("FT_DB_WRITERS");
-        const int v = e ? atoi(e) : 2;
-        return v < 1 ? 1 : (v > MAX_WRITERS ? MAX_WRITERS : v);
-    }();
+        const int v = e ? atoi(e) : (features_per_stream >= 1024 ? MAX_WRITERS : 2);
+        N_WRITERS = v < 1 ? 1 : (v > MAX_WRITERS ? MAX_WRITERS : v);
+    }
     struct DbJob {
         std::vector<TrackKLT::MonoPlan> payload;
         std::atomic<int> remaining{0};
@@ -568,6 +572,7 @@ int ftk_batch_create_grouped(ftk_batch** out, int device, const ftk_options* o, 
             G.be.reset(ftk_make_backend(device, limits_for(*o, G.n, max_width, max_height, 3), &G.device_ctx));
             if (!G.be) return FT_E_NODEVICE;
             G.batch.reset(new TrackKLTBatch(G.be.get(), to_options(*o), G.n, per_group, 3));
+            G.choose_writers(o->num_pts);
         }
         for (auto& g : b->groups) g->start();
         *out = b.release();
