@@ -6,7 +6,12 @@ Every run is `bench.py --workload <workload> --groups 1 ...`, so every dispatch 
 frames; the tracking and rejection kernels are counted per point (lk_kernel runs one wavefront per point: points of a
 dispatch = grid size / 64, less the few wavefronts that round the grid up to a multiple of 8).  FETCH_SIZE and
 WRITE_SIZE are in KiB; gfx950 reports half the bytes of 128-byte line requests in FETCH_SIZE, so it is doubled.
-Prints one JSON object: {"workload", "traffic": {kind: [bytes, unit]}, "valu": {kind: [wave instructions, unit]}, "kernels": {...}}"""
+Prints one JSON object: {"workload", "traffic": {kind: [bytes, unit]}, "valu": {kind: [wave instructions, unit]}, "kernels": {...}}
+
+    python tools/pmc_per_unit.py --install <tag> <workload> [<workload> ...]
+
+copies gpurun_out/prof_<tag>/pmc_per_unit_<workload>.json to profiles/<tag>_pmc_per_unit_<workload>.json and writes their
+"traffic" and "valu" tables into profiles/pmc_per_unit.json, the file bench.py reads."""
 import csv
 import glob
 import json
@@ -42,7 +47,24 @@ def collect(d):
     return out
 
 
+def install(tag, workloads):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    merged = {"note": "per-unit figures of the rocprofv3 counter passes of tools/profile_r3.sh (one-group runs of bench.py, 64 streams per launch): "
+                      "FETCH_SIZE and WRITE_SIZE in runs of their own, FETCH_SIZE doubled (gfx950 counts half the bytes of 128-byte line requests), "
+                      "SQ_INSTS_VALU per wavefront; raw summaries: profiles/%s_pmc_per_unit_<workload>.json" % tag, "workloads": {}}
+    for wl in workloads:
+        with open(os.path.join(root, "gpurun_out", "prof_" + tag, "pmc_per_unit_%s.json" % wl)) as f:
+            one = json.load(f)
+        with open(os.path.join(root, "profiles", "%s_pmc_per_unit_%s.json" % (tag, wl)), "w") as f:
+            json.dump(one, f, indent=1, sort_keys=True)
+        merged["workloads"][wl] = {"traffic": one["traffic"], "valu": one["valu"]}
+    with open(os.path.join(root, "profiles", "pmc_per_unit.json"), "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
+
+
 def main():
+    if sys.argv[1] == "--install":
+        return install(sys.argv[2], sys.argv[3:])
     workload, streams = sys.argv[1], int(sys.argv[2])
     fetch, write, insts = collect(sys.argv[3]), collect(sys.argv[4]), collect(sys.argv[5])
 
