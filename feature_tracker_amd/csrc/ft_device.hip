@@ -142,6 +142,7 @@ struct ft_ctx {
 
     // timing
     int profile = 0;   // bit 0: time kernel groups with events, bit 1: count LK work (iteration counters)
+    bool lk_fused_fb = true;  // forward-backward tracking in one launch (FT_LK_FUSED_FB=0: two launches)
     int lk_pair_max = 2048;   // points per tracking launch up to which lk_pair_kernel runs (FT_LK_PAIR_MAX overrides it: 0 = never)
     std::vector<EventPair> ev_inflight;
     std::vector<EventPair> ev_pool;
@@ -376,17 +377,25 @@ static int stage_rows(ft_ctx* c, int si, const uint8_t* host, int w, int h, size
     return FT_OK;
 }
 
-template <int SEGLEN>
+template <int SEGLEN, bool FUSED>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
     // Up to one wavefront pair per wave slot pair of the device the two-wave form is the faster one (its chain of
     // dependent steps is a third shorter); beyond that the idle halves of the pairs cost more than the chain saves.
     if (total <= c->lk_pair_max) {
-        if (a.win_h > 21) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
-        else hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        if (a.win_h > 21) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, true, FUSED>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        else hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false, FUSED>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
         return;
     }
-    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
-    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true, FUSED>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false, FUSED>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+}
+template <bool FUSED>
+static void launch_lk_seglen(ft_ctx* c, const LKArgs& a, int total, int seglen) {
+    switch (seglen) {
+        case 4: launch_lk<4, FUSED>(c, a, total); break;
+        case 8: launch_lk<8, FUSED>(c, a, total); break;
+        default: launch_lk<16, FUSED>(c, a, total); break;
+    }
 }
 
 }  // namespace
@@ -428,6 +437,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->device = device;
     c->lim = *lim;
     if (const char* e = getenv("FT_LK_PAIR_MAX")) c->lk_pair_max = atoi(e);
+    if (const char* e = getenv("FT_LK_FUSED_FB")) c->lk_fused_fb = atoi(e) != 0;
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);
     if (hipStreamCreateWithFlags(&c->q_, hipStreamNonBlocking) != hipSuccess) return fail(FT_E_HIP);
@@ -896,13 +906,14 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     EventPair ep;
     prof_begin(c, 1, ep);
-    for (int pass = 0; pass < (fb ? 2 : 1); pass++) {
-        a.backward = pass;
-        if (pass == 1) a.iters = nullptr;
-        switch (seglen) {
-            case 4: launch_lk<4>(c, a, (int)N); break;
-            case 8: launch_lk<8>(c, a, (int)N); break;
-            default: launch_lk<16>(c, a, (int)N); break;
+    if (fb && c->lk_fused_fb) {
+        // forward and backward pass of every feature in one launch, by the same wavefront(s)
+        launch_lk_seglen<true>(c, a, (int)N, seglen);
+    } else {
+        for (int pass = 0; pass < (fb ? 2 : 1); pass++) {
+            a.backward = pass;
+            if (pass == 1) a.iters = nullptr;
+            launch_lk_seglen<false>(c, a, (int)N, seglen);
         }
     }
     prof_end(c, ep);

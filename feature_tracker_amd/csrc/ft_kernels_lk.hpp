@@ -688,12 +688,12 @@ __device__ __forceinline__ void lk_template(const LkWave<SEGLEN>& W, const uint3
 // multiply (together within 1e-6 of the trace over the area, relative) decide it whenever the value is clear of the
 // threshold by four times that; the correctly rounded square root and division run only in that band.
 template <int SEGLEN>
-__device__ __forceinline__ int lk_matrix_test(const LKArgs& a, const LkWave<SEGLEN>& W, int level, float A11, float A12, float A22, float& eig_value) {
+__device__ __forceinline__ int lk_matrix_test(const LKArgs& a, const LkWave<SEGLEN>& W, int bwd, int level, float A11, float A12, float A22, float& eig_value) {
     const float D = A11 * A22 - A12 * A12;
     const float eig_tr = A22 + A11, eig_disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
     bool eig_low;
     const float approx = (eig_tr - __builtin_amdgcn_sqrtf(eig_disc)) * W.inv_area;
-    const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward;
+    const bool want_value = (a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !bwd;
     if (!want_value && fabsf(approx - W.min_eig_f) > (eig_tr * W.inv_area + W.min_eig_f) * 4e-6f) {
         eig_low = approx < W.min_eig_f;
     } else {
@@ -707,7 +707,7 @@ __device__ __forceinline__ int lk_matrix_test(const LKArgs& a, const LkWave<SEGL
 // Newton iterations of one level on the staged J region R (re-staged when the window walks out of it), the per-level
 // iteration count, and at level 0 the residual at the final position.
 template <int SEGLEN, bool TALL>
-__device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEGLEN>& W, int pt, int level, uint32_t* __restrict__ jlds,
+__device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEGLEN>& W, int bwd, int pt, int level, uint32_t* __restrict__ jlds,
                                                const uint8_t* __restrict__ imgJ, uint32_t ipitch, int w, int h, const int (&Cw)[SEGLEN],
                                                const uint32_t (&GX)[SEGLEN / 2], const uint32_t (&GY)[SEGLEN / 2], float A11, float A12, float A22,
                                                Region& R, float nx, float ny, float& outx, float& outy, int& st, float& errv) {
@@ -777,10 +777,10 @@ __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEG
         }
         pdx = dx; pdy = dy;
     }
-    if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
+    if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = n_iter;
 
     // ---- residual at the final position (level 0 only) ----
-    if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !a.backward) {
+    if (st && level == 0 && !(a.flags & FT_LK_GET_MIN_EIGENVALS) && !bwd) {
         const float qx = outx - half_x, qy = outy - half_y;
         const int iqx = lk_uniform_floor(qx), iqy = lk_uniform_floor(qy);
         if (iqx < -ww || iqx >= w || iqy < -wh || iqy >= h) {
@@ -821,12 +821,36 @@ __device__ __forceinline__ void lk_write_result(const LKArgs& a, int pt, const L
         if (!st || !(d2 <= a.fb_thresh2)) a.status[pt] = 0;
     }
 }
+
+// Forward and backward pass of a feature in one launch (FUSED): the backward pass of a feature needs nothing but that
+// feature's forward result, so the wavefront that found it goes straight on, with the result in registers: template =
+// the target pyramid at the forward result, target = the template pyramid, first guess = the original point.  The
+// values are those a second launch reads back from memory, so every result is the same; what goes away is the second
+// launch with its start and its end.  A feature whose forward track failed keeps status 0 whatever a backward pass
+// finds, so it gets none.
+// The forward result (x, y, residual) waits in LDS, written and read back by lane 0 of the same wavefront; the
+// positions that steer the backward pass are the same in all lanes and stay in scalar registers.
+__device__ __forceinline__ float lk_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ void lk_turn_around(LkPoint& P, float outx, float outy) {
+    const float ox = P.tx, oy = P.ty;
+    P.tx = lk_uniform(outx); P.ty = lk_uniform(outy); P.gx0 = ox; P.gy0 = oy; P.use_init = true;
+    const int t = P.img_I; P.img_I = P.img_J; P.img_J = t;
+}
+__device__ __forceinline__ void lk_write_fused(const LKArgs& a, int pt, const LkPoint& P, const float* fwd, float outx, float outy, int st) {
+    const float dx = outx - P.gx0, dy = outy - P.gy0;
+    const float d2 = dx * dx + dy * dy;
+    a.next_xy[2 * pt] = fwd[0];
+    a.next_xy[2 * pt + 1] = fwd[1];
+    a.status[pt] = (uint8_t)((st && d2 <= a.fb_thresh2) ? 1 : 0);
+    a.err[pt] = fwd[2];
+}
 #undef LK_WAVE_LOCALS
 
 // All levels of one feature on one wavefront.  SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more
-// staged rows per lane).  jlds / ilds: the wavefront's LDS arrays for the target and the template region.
-template <int SEGLEN, bool TALL>
-__device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, uint32_t* __restrict__ jlds, uint32_t* __restrict__ ilds) {
+// staged rows per lane); FUSED: forward pass, then the backward pass of the same feature (launched with a.backward = 0).
+// jlds / ilds: the wavefront's LDS arrays for the target and the template region.
+template <int SEGLEN, bool TALL, bool FUSED>
+__device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, uint32_t* __restrict__ jlds, uint32_t* __restrict__ ilds, float* __restrict__ fwd) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
     constexpr int J_ROWS = (WH_MAX + 1 + 2 * LK_MARGIN + 3) / 4;    // staged rows per lane, target region
@@ -834,6 +858,9 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
     LkWave<SEGLEN> W;
     LkPoint P;
     lk_prologue<SEGLEN>(a, pt, lane, W, P);
+    int bwd = a.backward;               // direction of the pass that runs now
+#pragma nounroll
+    for (;;) {
     float outx = P.gx0, outy = P.gy0;   // nextPts[i]
     int st = 1;
     float errv = 0.f;
@@ -842,7 +869,7 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
         const LkLevel G = lk_level<SEGLEN>(a, W, P, level, outx, outy);
         if (G.tmpl_out) {
             if (level == 0) { st = 0; errv = 0.f; }
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
+            if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             continue;
         }
         // ---- stage both regions of this level: their loads are in flight together ----
@@ -877,17 +904,32 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
         float A11, A12, A22;
         lk_template<SEGLEN, TALL>(W, ilds, RI, G.px, G.py, G.ipx, G.ipy, w, h, Cw, GX, GY, A11, A12, A22);
         float eig_value = 0.f;
-        const int code = lk_matrix_test<SEGLEN>(a, W, level, A11, A12, A22, eig_value);
-        if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = eig_value;
+        const int code = lk_matrix_test<SEGLEN>(a, W, bwd, level, A11, A12, A22, eig_value);
+        if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !bwd) errv = eig_value;
         if (code != 0) {
             if (level == 0) st = 0;
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
+            if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             continue;
         }
-        lk_track_level<SEGLEN, TALL>(a, W, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
+        lk_track_level<SEGLEN, TALL>(a, W, bwd, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
         __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
     }
-    if (lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
+    if (!FUSED) {
+        if (lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
+        break;
+    }
+    if (bwd) {
+        if (lane == 0) lk_write_fused(a, pt, P, fwd, outx, outy, st);
+        break;
+    }
+    if (!__builtin_amdgcn_readfirstlane(st)) {   // (the same in all lanes)
+        if (lane == 0) lk_write_result(a, pt, P, outx, outy, 0, errv);
+        break;
+    }
+    if (lane == 0) { fwd[0] = outx; fwd[1] = outy; fwd[2] = errv; }
+    lk_turn_around(P, outx, outy);
+    bwd = 1;
+    }
 }
 
 // One wavefront per feature, one single-wavefront workgroup each: the hardware dispatcher hands a free wave slot its
@@ -896,7 +938,7 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
 // atomics per counter, performed memory-side, cost more than the dispatches they replace), features dealt to the
 // resident wavefronts in fixed strides 88 us (no counters, but no balancing either).  Wavefronts that stay warm gain
 // nothing: the launch is bound by vector issue between its ends, and its ends by one wavefront's dependent chain.
-template <int SEGLEN, bool TALL>
+template <int SEGLEN, bool TALL, bool FUSED>
 __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;
@@ -906,7 +948,8 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     __shared__ uint32_t ilds[(4 * I_ROWS + 1) * LK_PITCH + 4];  // template region: window + Scharr apron
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
-    lk_one_point<SEGLEN, TALL>(a, pt, threadIdx.x, jlds, ilds);
+    __shared__ float fwd[3];                                     // FUSED: the forward result during the backward pass
+    lk_one_point<SEGLEN, TALL, FUSED>(a, pt, threadIdx.x, jlds, ilds, fwd);
 }
 
 // The same tracking with two wavefronts per feature.  The template of a level (staging of the I region, Scharr patch,
@@ -916,8 +959,10 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
 // matrix, the outcome of its tests).  Both waves pass the same two workgroup barriers in every level, whatever the
 // level's outcome: the first says "the template is in LDS", the second "the tracker has taken it"; in between only
 // the tracker touches the hand-over area, outside only the templater.  The chain of dependent steps of a feature gets
-// a third shorter; the arithmetic, and so every result, is that of lk_kernel.
-template <int SEGLEN, bool TALL>
+// a third shorter; the arithmetic, and so every result, is that of lk_kernel.  FUSED: after the forward pass the
+// tracker hands its result to the templater through LDS (one more barrier for both) and both go through the levels
+// again for the backward pass.
+template <int SEGLEN, bool TALL, bool FUSED>
 __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
@@ -928,6 +973,8 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     __shared__ uint32_t hand[2 * SEGLEN * 64];                  // hand-over: Cw[SEGLEN], GX[SEGLEN/2], GY[SEGLEN/2] of every lane
     __shared__ float hand_f[4];                                 // A11, A12, A22, smaller eigenvalue (when asked for)
     __shared__ int hand_code;                                   // 0: template ready, 1: window outside the image, 2: matrix tests failed
+    __shared__ float turn_f[3];                                 // FUSED: forward result (x, y, residual) ...
+    __shared__ int turn_st;                                     // ... and status, from the tracker to the templater
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     const int lane = threadIdx.x & 63;
@@ -935,6 +982,9 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     LkWave<SEGLEN> W;
     LkPoint P;
     lk_prologue<SEGLEN>(a, pt, lane, W, P);
+    int bwd = a.backward;               // direction of the pass that runs now
+#pragma nounroll
+    for (;;) {
     float outx = P.gx0, outy = P.gy0;   // nextPts[i]
     int st = 1;
     float errv = 0.f;
@@ -956,7 +1006,7 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
                 const Region RI = stage_region<I_ROWS, LK_PITCH>(ilds, G.imgI, G.ipitch, w, h, G.ipx - 1, G.ipx + W.ext_w + 1, G.ipy - 1, W.wh + 3, lane, W.reach_w, W.reach_h);
                 lds_fence();
                 lk_template<SEGLEN, TALL>(W, ilds, RI, G.px, G.py, G.ipx, G.ipy, w, h, Cw, GX, GY, A11, A12, A22);
-                code = lk_matrix_test<SEGLEN>(a, W, level, A11, A12, A22, eig_value);
+                code = lk_matrix_test<SEGLEN>(a, W, bwd, level, A11, A12, A22, eig_value);
 #pragma unroll
                 for (int k = 0; k < SEGLEN; k++) hand[k * 64 + lane] = (uint32_t)Cw[k];
 #pragma unroll
@@ -994,19 +1044,36 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
 
         if (code == 1) {            // the template window lies outside the image
             if (level == 0) { st = 0; errv = 0.f; }
-            if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
+            if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
         } else {
-            if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !a.backward) errv = eig_value;
+            if ((a.flags & FT_LK_GET_MIN_EIGENVALS) && level == 0 && !bwd) errv = eig_value;
             if (code == 2) {        // flat or degenerate template
                 if (level == 0) st = 0;
-                if (a.iters && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
+                if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             } else {
-                lk_track_level<SEGLEN, TALL>(a, W, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
+                lk_track_level<SEGLEN, TALL>(a, W, bwd, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
                 __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
             }
         }
     }
-    if (!templater && lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
+    if (!FUSED) {
+        if (!templater && lane == 0) lk_write_result(a, pt, P, outx, outy, st, errv);
+        break;
+    }
+    if (bwd) {
+        if (!templater && lane == 0) lk_write_fused(a, pt, P, turn_f, outx, outy, st);
+        break;
+    }
+    // the forward result from the tracker to the templater (written once per feature, so one barrier is enough)
+    if (!templater && lane == 0) { turn_f[0] = outx; turn_f[1] = outy; turn_f[2] = errv; turn_st = st; }
+    __syncthreads();
+    if (!turn_st) {
+        if (!templater && lane == 0) lk_write_result(a, pt, P, outx, outy, 0, errv);
+        break;
+    }
+    lk_turn_around(P, turn_f[0], turn_f[1]);
+    bwd = 1;
+    }
 }
 
 // input block of a tracking batch: pinned host memory (read through its device address) -> device memory, 16 bytes
