@@ -191,7 +191,9 @@ def test_lk_initial_guess_no_initial_flow_and_min_eig(dev, lk_form):
         assert (ref[1] == 0).any()
 
 
-def test_lk_forward_backward_and_rect_window(dev, lk_form):
+def test_lk_forward_backward_and_rect_window(dev, lk_form, monkeypatch):
+    """Forward-backward tracking equals the checker's, in one launch (the default: a feature's wavefronts go on with
+    its backward pass) and in two launches (FT_LK_FUSED_FB=0, read when the context is created)."""
     w, h = 640, 360
     prev, nxt = synth.shifted_pair(w, h, dx=3, dy=2, seed=60)
     nxt = nxt.copy()
@@ -208,6 +210,16 @@ def test_lk_forward_backward_and_rect_window(dev, lk_form):
             out = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=4, flags=flags, fb_thresh=1.0))[0]
         _compare_lk(out, ref)
         assert 0 < (ref[1] == 0).sum() < len(pts)
+        if win in (21, (21, 11)):
+            monkeypatch.setenv("FT_LK_FUSED_FB", "0")
+            with _ctx(dev, w, h) as ctx:
+                ctx.upload(0, 0, prev)
+                ctx.upload(0, 1, nxt)
+                ctx.build_pyramid([0, 0], [0, 1], 4, win)
+                two = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=4, flags=flags, fb_thresh=1.0))[0]
+            monkeypatch.delenv("FT_LK_FUSED_FB")
+            for a, b in zip(out, two):
+                assert np.array_equal(a, b)
 
 
 def test_lk_batched_jobs_and_gyro_seed(dev, lk_form):
