@@ -142,6 +142,7 @@ struct ft_ctx {
 
     // timing
     int profile = 0;   // bit 0: time kernel groups with events, bit 1: count LK work (iteration counters)
+    int lk_direct_max = 1024; // points per tracking launch up to which the input block is read in place from pinned memory (FT_LK_DIRECT_MAX)
     bool lk_fused_fb = true;  // forward-backward tracking in one launch (FT_LK_FUSED_FB=0: two launches)
     int lk_pair_max = 2048;   // points per tracking launch up to which lk_pair_kernel runs (FT_LK_PAIR_MAX overrides it: 0 = never)
     std::vector<EventPair> ev_inflight;
@@ -437,6 +438,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->device = device;
     c->lim = *lim;
     if (const char* e = getenv("FT_LK_PAIR_MAX")) c->lk_pair_max = atoi(e);
+    if (const char* e = getenv("FT_LK_DIRECT_MAX")) c->lk_direct_max = atoi(e);
     if (const char* e = getenv("FT_LK_FUSED_FB")) c->lk_fused_fb = atoi(e) != 0;
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);
@@ -855,10 +857,12 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
 
     // Large batches: one transfer for the whole block (jobs .. end of next_xy in use), so that the tracking waves read
     // their inputs from device memory.  Small batches (a single stream's worth of points) read the pinned block in
-    // place: the extra dependent launch would cost more than the few reads over the bus.  (Not with the outlier
-    // rejection behind the tracking: its workgroups read the job records and points over the bus as well, and the
-    // single-stream latency went from 77 to 83 us, 8 streams from 16.9 to 16.3 M features/s.)
-    const bool direct_in = N <= 1024 && !stereo && !reject;
+    // place: the extra dependent launch would cost more than the few reads over the bus.  With the outlier rejection
+    // behind the tracking, the tracking wavefronts leave device copies of the job records and the template points for
+    // it (its workgroups reading them over the bus as well cost more than the launch saved: single-stream latency 77
+    // -> 83 us, 8 streams 16.9 -> 16.3 M features/s).
+    const bool direct_in = N <= (size_t)c->lk_direct_max && !stereo;
+    const bool echo = direct_in && reject;
     const uint8_t* ib = direct_in ? c->lk_in_host_dev : c->lk_in_dev;
     if (!direct_in) {
         // (every job seeded by its homography: the kernel never looks at the guesses, and they stay behind)
@@ -898,6 +902,9 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     a.max_iter = std::min(std::max(prm->max_iter, 0), 100);
     a.flags = prm->flags;
     a.backward = 0;
+    a.echo_jobs = echo ? reinterpret_cast<LKJobDev*>(c->lk_in_dev) : nullptr;
+    a.echo_prev_xy = echo ? reinterpret_cast<float*>(c->lk_in_dev + off_prev) : nullptr;
+    a.n_jobs = n_jobs;
     a.fb_thresh2 = prm->fb_thresh * prm->fb_thresh;
     const double eps = std::min(std::max(prm->eps, 0.), 10.);
     a.epsilon = eps * eps;
@@ -912,7 +919,7 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     } else {
         for (int pass = 0; pass < (fb ? 2 : 1); pass++) {
             a.backward = pass;
-            if (pass == 1) a.iters = nullptr;
+            if (pass == 1) { a.iters = nullptr; a.echo_jobs = nullptr; a.echo_prev_xy = nullptr; }
             launch_lk_seglen<false>(c, a, (int)N, seglen);
         }
     }
@@ -933,8 +940,8 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     if (reject) {
         // final mask on the device; the kernel also moves positions, residuals and status into the pinned host block
         OutlierArgs o;
-        o.jobs = a.jobs;
-        o.prev_xy = a.prev_xy; o.next_xy = a.next_xy; o.err = a.err; o.status = a.status;
+        o.jobs = echo ? reinterpret_cast<const LKJobDev*>(c->lk_in_dev) : a.jobs;
+        o.prev_xy = echo ? reinterpret_cast<const float*>(c->lk_in_dev + off_prev) : a.prev_xy; o.next_xy = a.next_xy; o.err = a.err; o.status = a.status;
         o.norm = c->lk_norm_dev;
         o.out_xy = reinterpret_cast<float*>(c->lk_out_host_dev);
         o.out_err = reinterpret_cast<float*>(c->lk_out_host_dev + 8 * N);

@@ -52,6 +52,12 @@ struct LKArgs {
     int max_iter;
     int flags;
     int backward;             // 0: forward pass, 1: forward-backward verification pass
+    // When the input block above is read in place from pinned host memory and a kernel that also needs the job records
+    // and the template points runs behind this one (the outlier rejection), the tracking wavefronts leave device copies:
+    // wavefront pt copies its template point and the job records pt, pt + total, ...  Null: no copies.
+    LKJobDev* echo_jobs;
+    float* echo_prev_xy;
+    int n_jobs;
     float fb_thresh2;
     double epsilon;           // squared
     double min_eig;
@@ -236,6 +242,7 @@ __device__ __forceinline__ Region region_of(int x_first, int x_last, int y_first
 __device__ __forceinline__ bool region_cols_inside(const Region& R, int w) { return R.rx0 >= 0 && R.rx0 + 4 * LK_RW_DWORDS <= w; }
 __device__ __forceinline__ bool region_rows_inside(const Region& R, int h) { return R.ry0 >= 0 && R.ry0 + R.rh <= h; }
 struct __attribute__((packed, aligned(4))) LkU128Unaligned { uint32_t a, b, c, d; };
+static_assert(sizeof(LKJobDev) % 8 == 0 && sizeof(LKJobDev) / 8 <= 64, "a job record is copied by one wavefront, eight bytes per lane");
 static_assert(LK_RW_DWORDS == 12, "three 16-byte pieces per staged row");
 template <int MAXR> struct LkInteriorRows { LkU128Unaligned v[(4 * MAXR + 20) / 21]; };
 // Columns inside the image.  ROWS_INSIDE: so are the rows; otherwise rows are mirrored (REFLECT_101, one reflection:
@@ -467,7 +474,7 @@ struct LkPoint {
     (void)row_ok; (void)half_x; (void)half_y; (void)eps_f; (void)eps_band; (void)inv_area; (void)min_eig_f; (void)keep; (void)FLT_SCALE;
 
 template <int SEGLEN>
-__device__ __forceinline__ void lk_prologue(const LKArgs& a, int pt, int lane, LkWave<SEGLEN>& W, LkPoint& P) {
+__device__ __forceinline__ void lk_prologue(const LKArgs& a, int pt, int lane, LkWave<SEGLEN>& W, LkPoint& P, bool echo = true) {
     const int ww = a.win_w, wh = a.win_h;
     const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
     const int x0 = s * SEGLEN;
@@ -516,6 +523,11 @@ __device__ __forceinline__ void lk_prologue(const LKArgs& a, int pt, int lane, L
         }
     }
 
+    if (a.echo_jobs && echo) {   // (the same for the whole wavefront)
+        if (lane == 0) { a.echo_prev_xy[2 * pt] = a.prev_xy[2 * pt]; a.echo_prev_xy[2 * pt + 1] = a.prev_xy[2 * pt + 1]; }
+        for (int j = pt; j < a.n_jobs; j += a.total)
+            if (lane < (int)(sizeof(LKJobDev) / 8)) reinterpret_cast<uint64_t*>(a.echo_jobs + j)[lane] = reinterpret_cast<const uint64_t*>(a.jobs + j)[lane];
+    }
     const float eps_f = (float)a.epsilon, eps_band = eps_f * 1e-4f + 1e-30f;
     const float inv_area = 1.f / (float)(2 * ww * wh), min_eig_f = (float)a.min_eig;
     W.lane = lane; W.ww = ww; W.wh = wh; W.r = r; W.s = s; W.x0 = x0; W.rc = rc; W.ext_w = ext_w; W.reach_w = reach_w; W.reach_h = reach_h;
@@ -981,7 +993,7 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     const bool templater = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) != 0;
     LkWave<SEGLEN> W;
     LkPoint P;
-    lk_prologue<SEGLEN>(a, pt, lane, W, P);
+    lk_prologue<SEGLEN>(a, pt, lane, W, P, !templater);
     int bwd = a.backward;               // direction of the pass that runs now
 #pragma nounroll
     for (;;) {
