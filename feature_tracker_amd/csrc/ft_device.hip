@@ -79,6 +79,14 @@ struct ft_ctx {
     // chain host preparation -> tracking -> outlier rejection -> host bookkeeping, and the next set's front work
     // already runs on the device while the host does its part of that chain.
     hipStream_t q_ = nullptr;            // use enq(ctx) to put work on it
+    // Optional second queue for the work that does not depend on tracking results (frame ingest, pyramids, detector):
+    // see ft_set_front_queue.  cur_ is the queue enq() hands out (q_ outside a FrontScope); front_dirty_ says that the
+    // front queue holds work the main queue has not been told to wait for yet.
+    hipStream_t front_q_ = nullptr;
+    hipStream_t cur_ = nullptr;
+    hipEvent_t front_ev_ = nullptr;
+    bool front_enabled = false, front_dirty_ = false;
+    int front_env = -1;                  // FT_FRONT_QUEUE: 0 never, 1 from creation on, unset: as ft_set_front_queue says
     // Completion flag of the outlier-rejection kernel: its last workgroup stores a sequence number to pinned host
     // memory, and a fence taken while that launch is the newest work on the queue is waited for by polling the flag
     // (about 5 us sooner than through an event).
@@ -159,8 +167,34 @@ namespace {
 // the context's queue, for putting work on it: whatever is enqueued next is then the newest work on the queue
 inline hipStream_t enq(ft_ctx* c) {
     c->tail_flag_seq = 0;
+    if (c->cur_ != c->q_) return c->cur_;
+    if (c->front_dirty_) {   // everything put on the main queue from here on comes after the front queue's work so far
+        (void)hipStreamWaitEvent(c->q_, c->front_ev_, 0);
+        c->front_dirty_ = false;
+    }
     return c->q_;
 }
+
+// Inside one of these, enq() hands out the front queue (if the context has one switched on).  The caller's contract:
+// what the enclosed work writes (a pyramid ring slot, the detector's buffers) is not read by tracking work that is
+// still queued.  The other direction is kept here: the main queue waits for the front queue's latest work before
+// anything else is put on it.
+struct FrontScope {
+    ft_ctx* c;
+    bool on;
+    explicit FrontScope(ft_ctx* ctx) : c(ctx), on(ctx->front_enabled && ctx->front_q_ && ctx->cur_ == ctx->q_) {
+        if (on) c->cur_ = c->front_q_;
+    }
+    ~FrontScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->front_ev_, c->front_q_);
+        c->front_dirty_ = true;
+        c->cur_ = c->q_;
+        c->tail_flag_seq = 0;
+    }
+    FrontScope(const FrontScope&) = delete;
+    FrontScope& operator=(const FrontScope&) = delete;
+};
 
 #define FT_HIP(ctx, call)                                                                          \
     do {                                                                                           \
@@ -282,7 +316,9 @@ int deliver_pending(ft_ctx* c, uint64_t upto) {
 }
 
 int sync_and_deliver(ft_ctx* c) {
-    FT_HIP(c, hipStreamSynchronize(enq(c)));
+    if (c->front_q_) FT_HIP(c, hipStreamSynchronize(c->front_q_));   // (also when called from inside a FrontScope)
+    FT_HIP(c, hipStreamSynchronize(c->q_));
+    c->tail_flag_seq = 0;
     std::fill(c->stage_busy.begin(), c->stage_busy.end(), 0);
     std::fill(c->stage_batch_idx.begin(), c->stage_batch_idx.end(), -1);
     prof_collect(c);
@@ -443,6 +479,8 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);
     if (hipStreamCreateWithFlags(&c->q_, hipStreamNonBlocking) != hipSuccess) return fail(FT_E_HIP);
+    c->cur_ = c->q_;
+    if (const char* e = getenv("FT_FRONT_QUEUE")) c->front_env = atoi(e) != 0;
 
     // arena layout from the largest frame
     size_t off = 0;
@@ -550,6 +588,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->pf_host = (float*)p;
 
     if (hipEventCreate(&c->region_a) != hipSuccess || hipEventCreate(&c->region_b) != hipSuccess) return fail(FT_E_HIP);
+    if (c->front_env == 1 && ft_set_front_queue(c, 1) != FT_OK) return fail(FT_E_HIP);
     *out = c;
     return FT_OK;
 }
@@ -557,6 +596,9 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
 void ft_ctx_destroy(ft_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->front_q_) { (void)hipStreamSynchronize(c->front_q_); (void)hipStreamDestroy(c->front_q_); c->front_q_ = nullptr; }
+    if (c->front_ev_) (void)hipEventDestroy(c->front_ev_);
+    c->cur_ = c->q_; c->front_dirty_ = false;
     if (enq(c)) (void)hipStreamSynchronize(enq(c));
     for (auto& e : c->stage_done) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->stage_batch_ev) if (e) (void)hipEventDestroy(e);
@@ -594,6 +636,7 @@ int ft_upload(ft_ctx* c, int stream, int slot, const uint8_t* host, int w, int h
     if (si < 0) return FT_E_INVALID;
     if (w > c->lim.max_width || h > c->lim.max_height) return FT_E_LIMIT;
     FT_HIP(c, hipSetDevice(c->device));
+    FrontScope front(c);
     { const int rc = stage_rows(c, si, host, w, h, stride); if (rc) return rc; }
     uint8_t* st = c->stage + (size_t)si * c->stage_bytes_per_slot;
     uint8_t* dst = c->arena.base + (uint64_t)si * c->arena.slot_bytes + c->arena.lv[0].img_off;
@@ -615,6 +658,7 @@ int ft_set_frames_device(ft_ctx* c, int n, const int* streams, const int* slots,
         L.idx[i] = si;
     }
     FT_HIP(c, hipSetDevice(c->device));
+    FrontScope front(c);
     for (int first = 0; first < n; first += FRAME_PTRS) {
         const int m = std::min(FRAME_PTRS, n - first);
         FramePtrs F;
@@ -640,6 +684,7 @@ int ft_build_pyramid(ft_ctx* c, int n, const int* streams, const int* slots, int
     int rc = collect_images(c, n, streams, slots, L, w, h);
     if (rc) return rc;
     FT_HIP(c, hipSetDevice(c->device));
+    FrontScope front(c);
     const int top = achieved_level(w, h, win_w, win_h, max_level);
     rc = run_levels(c, L, w, h, top, true, with_gradients != 0);
     if (rc) return rc;
@@ -695,6 +740,7 @@ int ft_set_frames_device_pyramid(ft_ctx* c, int n, const int* streams, const int
         src[i] = static_cast<const uint8_t*>(dev[i]);
     }
     FT_HIP(c, hipSetDevice(c->device));
+    FrontScope front(c);
     return frames_to_pyramid(c, L, n, src, w, h, stride, max_level, win_w, win_h, achieved);
 }
 
@@ -721,6 +767,7 @@ int ft_set_frames_staged_pyramid(ft_ctx* c, int n, const int* streams, const int
         src[i] = c->stage_dev + (size_t)si * c->stage_bytes_per_slot;
     }
     FT_HIP(c, hipSetDevice(c->device));
+    FrontScope front(c);
     int rc;
     if (w % 16 == 0 && (size_t)n * w * h >= ((size_t)2 << 20)) {
         // Many frames: the bus is the limit, so the staged bytes cross it in one linear pass into level 0 and the
@@ -1066,6 +1113,7 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     const size_t need = (size_t)((G.size_x + 1) / 2) * ((G.size_y + 1) / 2);
     G.cand_cap = (int)std::min(need, c->cand_entries_per_img / (size_t)cells);
     FT_HIP(c, hipSetDevice(c->device));
+    FrontScope front(c);
     const int ring = c->fast_next;
     if (c->fast_pending[ring].active) {   // both host buffers hold undelivered results: finish the queue first
         rc = sync_and_deliver(c);
@@ -1262,9 +1310,22 @@ int ft_sync(ft_ctx* c) {
     return sync_and_deliver(c);
 }
 
+int ft_set_front_queue(ft_ctx* c, int on) {
+    if (!c) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    if (c->front_env == 0) on = 0;
+    if (on && !c->front_q_) {
+        FT_HIP(c, hipStreamCreateWithFlags(&c->front_q_, hipStreamNonBlocking));
+        FT_HIP(c, hipEventCreateWithFlags(&c->front_ev_, hipEventDisableTiming));
+    }
+    c->front_enabled = on != 0;
+    return FT_OK;
+}
+
 int ft_fence(ft_ctx* c, uint64_t* token) {
     if (!c || !token) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
+    if (c->front_dirty_) (void)enq(c);   // the fence covers the front queue's work as well
     const uint64_t id = ++c->fence_ids;
     ft_ctx::Fence& f = c->fences[id % ft_ctx::FENCE_RING];
     f.flag_seq = c->tail_flag_seq;   // the queue ends with a launch that reports its own completion: no event needed

@@ -38,6 +38,9 @@ public:
     // outputs of the async calls made before it are delivered; later work keeps running
     virtual int fence(uint64_t* token) = 0;
     virtual int wait(uint64_t token) = 0;
+    // run ingest, pyramids and detector on a device queue of their own, beside the tracking work (a backend without
+    // queues has nothing to do)
+    virtual int set_front_queue(bool) { return FT_OK; }
     virtual const char* name() const = 0;
 };
 

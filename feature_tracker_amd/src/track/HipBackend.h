@@ -58,6 +58,7 @@ public:
     int sync() override { return ft_sync(ctx_); }
     int fence(uint64_t* token) override { return ft_fence(ctx_, token); }
     int wait(uint64_t token) override { return ft_wait(ctx_, token); }
+    int set_front_queue(bool on) override { return ft_set_front_queue(ctx_, on ? 1 : 0); }
     const char* name() const override { return "hip-gfx950"; }
     ft_ctx* ctx() { return ctx_; }
 

@@ -246,6 +246,17 @@ int ft_sync(ft_ctx* ctx);
  * first waits for the whole queue).  No reference counterpart: the reference's OpenCV calls are synchronous. */
 int ft_fence(ft_ctx* ctx, uint64_t* token);
 int ft_wait(ft_ctx* ctx, uint64_t token);
+/* Second device queue for the work that does not depend on tracking results.  With on != 0, ft_upload,
+ * ft_set_frame_device, ft_set_frames_device, ft_set_frames_device_pyramid, ft_set_frames_staged_pyramid, ft_build_pyramid and
+ * ft_fast_grid_async put their work on a queue of their own, so that the next frame's pyramids and detector run
+ * beside the current frame's tracking instead of behind it.  Everything else stays on the context's queue and waits
+ * for that work before it starts; fences, ft_wait and ft_sync cover both queues.  The caller's part: a pyramid slot
+ * these calls write must not be an operand of tracking work that is still queued (a ring of three slots per stream
+ * does that for frame-to-frame tracking).  Worth it for one large stream alone on its device (1280x720 with 2 000
+ * features: + 15 %); batches of small streams lose a few per cent, and the device takes four queues with work at a
+ * time.  FT_FRONT_QUEUE=0 / 1 in the environment overrides the call.
+ * No reference counterpart: the reference's OpenCV calls are synchronous. */
+int ft_set_front_queue(ft_ctx* ctx, int on);
 
 /* Timing. ft_profile(ctx, mode): mode 1 brackets every kernel group with HIP events on the context's queue (adds a
  * little overhead; the kernels launched are exactly those of an unprofiled run); mode 2 counts the LK work instead

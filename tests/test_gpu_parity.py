@@ -222,6 +222,44 @@ def test_lk_forward_backward_and_rect_window(dev, lk_form, monkeypatch):
                 assert np.array_equal(a, b)
 
 
+@pytest.mark.gpu
+def test_front_queue_gives_the_same_results(dev):
+    """Pyramids and detector of the next frame on a queue of their own, enqueued while the current frame's tracking is
+    still queued (three ring slots, fences): keypoints, positions and status equal the one-queue run's."""
+    w, h = 640, 360
+    frames = [synth.shifted_pair(w, h, dx=2 * k, dy=k, seed=90)[1] for k in range(5)]
+    pts = synth.random_points(w, h, 1500, seed=91, border=12)
+
+    def run(front):
+        res = []
+        with _ctx(dev, w, h, n_streams=1, n_slots=3) as ctx:
+            ctx.set_front_queue(front)
+
+            def stage(k):   # ingest + pyramid of frame k into its ring slot
+                ctx.upload(0, k % 3, frames[k])
+                ctx.build_pyramid([0], [k % 3], 3, 21, with_gradients=False)
+
+            stage(0)
+            stage(1)
+            for k in range(1, len(frames)):
+                cur, last = k % 3, (k - 1) % 3
+                det = ctx.fast_grid([0], [cur], 20, 5, 4, 9, sync=False)
+                out = ctx.lk_track([dict(prev=(0, last), next=(0, cur), prev_xy=pts)], dev.LKParams(win=21, max_level=3), sync=False)[0]
+                tok = ctx.fence()
+                if k + 1 < len(frames):   # the next frame's front work goes in before this frame's tracking is waited for
+                    stage(k + 1)
+                ctx.wait(tok)
+                res.append((det[0].copy(), det[1].copy(), out[0].copy(), out[1].copy(), out[2].copy()))
+        return res
+
+    one, two = run(False), run(True)
+    assert len(one) == len(two) == len(frames) - 1
+    for a, b in zip(one, two):
+        assert a[1][0] > 50 and a[3].sum() > 1000
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 def test_lk_batched_jobs_and_gyro_seed(dev, lk_form):
     w, h = 376, 240
     K4 = np.array([300.0, 300.0, 188.0, 120.0], dtype=np.float32)
