@@ -151,6 +151,7 @@ struct ft_ctx {
     // timing
     int profile = 0;   // bit 0: time kernel groups with events, bit 1: count LK work (iteration counters)
     int lk_direct_max = 1024; // points per tracking launch up to which the input block is read in place from pinned memory (FT_LK_DIRECT_MAX)
+    bool lk_fixed_windows = true;   // kernels compiled for 21 x 21 and 15 x 15 windows (FT_LK_FIXED_WINDOWS=0: the general ones)
     bool lk_fused_fb = true;  // forward-backward tracking in one launch (FT_LK_FUSED_FB=0: two launches)
     int lk_pair_max = 2048;   // points per tracking launch up to which lk_pair_kernel runs (FT_LK_PAIR_MAX overrides it: 0 = never)
     std::vector<EventPair> ev_inflight;
@@ -414,24 +415,32 @@ static int stage_rows(ft_ctx* c, int si, const uint8_t* host, int w, int h, size
     return FT_OK;
 }
 
-template <int SEGLEN, bool FUSED>
+template <int SEGLEN, bool FUSED, int WIN>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
     // Up to one wavefront pair per wave slot pair of the device the two-wave form is the faster one (its chain of
     // dependent steps is a third shorter); beyond that the idle halves of the pairs cost more than the chain saves.
     if (total <= c->lk_pair_max) {
-        if (a.win_h > 21) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, true, FUSED>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
-        else hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false, FUSED>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        if (a.win_h > 21) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, true, FUSED, 0>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        else hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false, FUSED, WIN>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
         return;
     }
-    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true, FUSED>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
-    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false, FUSED>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+    if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true, FUSED, 0>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+    else hipLaunchKernelGGL((lk_kernel<SEGLEN, false, FUSED, WIN>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
 }
+// the windows with kernels of their own: 21 x 21 (8-pixel segments) and the reference's 15 x 15 (4-pixel segments)
 template <bool FUSED>
 static void launch_lk_seglen(ft_ctx* c, const LKArgs& a, int total, int seglen) {
+    const bool fixed = c->lk_fixed_windows && a.win_w == a.win_h;
     switch (seglen) {
-        case 4: launch_lk<4, FUSED>(c, a, total); break;
-        case 8: launch_lk<8, FUSED>(c, a, total); break;
-        default: launch_lk<16, FUSED>(c, a, total); break;
+        case 4:
+            if (fixed && a.win_w == 15) launch_lk<4, FUSED, 15>(c, a, total);
+            else launch_lk<4, FUSED, 0>(c, a, total);
+            break;
+        case 8:
+            if (fixed && a.win_w == 21) launch_lk<8, FUSED, 21>(c, a, total);
+            else launch_lk<8, FUSED, 0>(c, a, total);
+            break;
+        default: launch_lk<16, FUSED, 0>(c, a, total); break;
     }
 }
 
@@ -475,6 +484,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lim = *lim;
     if (const char* e = getenv("FT_LK_PAIR_MAX")) c->lk_pair_max = atoi(e);
     if (const char* e = getenv("FT_LK_DIRECT_MAX")) c->lk_direct_max = atoi(e);
+    if (const char* e = getenv("FT_LK_FIXED_WINDOWS")) c->lk_fixed_windows = atoi(e) != 0;
     if (const char* e = getenv("FT_LK_FUSED_FB")) c->lk_fused_fb = atoi(e) != 0;
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(FT_E_NODEVICE);

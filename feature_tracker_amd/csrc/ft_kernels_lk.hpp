@@ -473,14 +473,18 @@ struct LkPoint {
     (void)lane; (void)ww; (void)wh; (void)r; (void)s; (void)x0; (void)rc; (void)ext_w; (void)reach_w; (void)reach_h; (void)n_valid; \
     (void)row_ok; (void)half_x; (void)half_y; (void)eps_f; (void)eps_band; (void)inv_area; (void)min_eig_f; (void)keep; (void)FLT_SCALE;
 
-template <int SEGLEN>
+// WIN > 0: the window is WIN x WIN, known when the kernel is compiled (the usual sizes have kernels of their own: masks,
+// task counts and lane geometry then fold into constants); 0: the size comes with the launch arguments.
+template <int SEGLEN, int WIN>
 __device__ __forceinline__ void lk_prologue(const LKArgs& a, int pt, int lane, LkWave<SEGLEN>& W, LkPoint& P, bool echo = true) {
-    const int ww = a.win_w, wh = a.win_h;
-    const int r = (lane * a.segs_inv) >> 16, s = lane - r * a.segs;   // lane / segs by reciprocal: exact for lane < 64
+    const int ww = WIN ? WIN : a.win_w, wh = WIN ? WIN : a.win_h;
+    const int segs = WIN ? (WIN + SEGLEN - 1) / SEGLEN : a.segs;
+    const int segs_inv = WIN ? (65536 + segs - 1) / segs : a.segs_inv;
+    const int r = (lane * segs_inv) >> 16, s = lane - r * segs;   // lane / segs by reciprocal: exact for lane < 64
     const int x0 = s * SEGLEN;
     const bool row_ok = r < wh;
     const int rc = row_ok ? r : wh - 1;          // lanes below the window reuse its last row (results masked)
-    const int ext_w = a.segs * SEGLEN;           // columns the lanes touch: [0, ext_w]
+    const int ext_w = segs * SEGLEN;             // columns the lanes touch: [0, ext_w]
     const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
     // smallest level size for which a staged region needs at most one reflection per axis (with some slack)
     const int reach_w = ext_w + 2 * LK_MARGIN + 8, reach_h = wh + 2 * LK_MARGIN + 8;
@@ -861,7 +865,7 @@ __device__ __forceinline__ void lk_write_fused(const LKArgs& a, int pt, const Lk
 // All levels of one feature on one wavefront.  SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more
 // staged rows per lane); FUSED: forward pass, then the backward pass of the same feature (launched with a.backward = 0).
 // jlds / ilds: the wavefront's LDS arrays for the target and the template region.
-template <int SEGLEN, bool TALL, bool FUSED>
+template <int SEGLEN, bool TALL, bool FUSED, int WIN>
 __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, uint32_t* __restrict__ jlds, uint32_t* __restrict__ ilds, float* __restrict__ fwd) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
@@ -869,7 +873,7 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
     constexpr int LK_PITCH = LkPitch<SEGLEN>::value;
     LkWave<SEGLEN> W;
     LkPoint P;
-    lk_prologue<SEGLEN>(a, pt, lane, W, P);
+    lk_prologue<SEGLEN, WIN>(a, pt, lane, W, P);
     int bwd = a.backward;               // direction of the pass that runs now
 #pragma nounroll
     for (;;) {
@@ -950,7 +954,7 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
 // atomics per counter, performed memory-side, cost more than the dispatches they replace), features dealt to the
 // resident wavefronts in fixed strides 88 us (no counters, but no balancing either).  Wavefronts that stay warm gain
 // nothing: the launch is bound by vector issue between its ends, and its ends by one wavefront's dependent chain.
-template <int SEGLEN, bool TALL, bool FUSED>
+template <int SEGLEN, bool TALL, bool FUSED, int WIN>
 __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;
@@ -961,7 +965,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     __shared__ float fwd[3];                                     // FUSED: the forward result during the backward pass
-    lk_one_point<SEGLEN, TALL, FUSED>(a, pt, threadIdx.x, jlds, ilds, fwd);
+    lk_one_point<SEGLEN, TALL, FUSED, WIN>(a, pt, threadIdx.x, jlds, ilds, fwd);
 }
 
 // The same tracking with two wavefronts per feature.  The template of a level (staging of the I region, Scharr patch,
@@ -974,7 +978,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
 // a third shorter; the arithmetic, and so every result, is that of lk_kernel.  FUSED: after the forward pass the
 // tracker hands its result to the templater through LDS (one more barrier for both) and both go through the levels
 // again for the backward pass.
-template <int SEGLEN, bool TALL, bool FUSED>
+template <int SEGLEN, bool TALL, bool FUSED, int WIN>
 __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
@@ -993,7 +997,7 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     const bool templater = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) != 0;
     LkWave<SEGLEN> W;
     LkPoint P;
-    lk_prologue<SEGLEN>(a, pt, lane, W, P, !templater);
+    lk_prologue<SEGLEN, WIN>(a, pt, lane, W, P, !templater);
     int bwd = a.backward;               // direction of the pass that runs now
 #pragma nounroll
     for (;;) {
