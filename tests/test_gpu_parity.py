@@ -143,7 +143,9 @@ def _compare_lk(gpu, ref, min_agree=STATUS_AGREE):
 
 @pytest.mark.parametrize("win,max_level,shape,n", [(21, 3, (480, 752), 150), (15, 3, (480, 752), 150), (21, 4, (720, 1280), 2000),
                                                     (9, 2, (240, 320), 300), (31, 2, (480, 752), 200)])
-def test_lk_matches_oracle(dev, win, max_level, shape, n, lk_form):
+def test_lk_matches_oracle(dev, win, max_level, shape, n, lk_form, monkeypatch):
+    """Every window runs the general kernels; 21 x 21 and 15 x 15 also have kernels compiled for that size, which are the
+    default for them (FT_LK_FIXED_WINDOWS=0, read when the context is created, keeps them on the general ones)."""
     h, w = shape
     prev, nxt = synth.shifted_pair(w, h, dx=4, dy=-3, seed=40 + win)
     nxt = np.clip(nxt.astype(np.int16) + np.random.default_rng(1).integers(-3, 4, nxt.shape), 0, 255).astype(np.uint8)
@@ -158,6 +160,16 @@ def test_lk_matches_oracle(dev, win, max_level, shape, n, lk_form):
     _compare_lk(out, ref)
     assert np.array_equal(out[3], ref[3])          # identical iteration counts per level
     assert np.array_equal(out[0], ref[0])          # exact sums on both sides: positions are bit-identical
+    if win in (21, 15):
+        monkeypatch.setenv("FT_LK_FIXED_WINDOWS", "0")
+        with _ctx(dev, w, h) as ctx:
+            ctx.upload(0, 0, prev)
+            ctx.upload(0, 1, nxt)
+            ctx.build_pyramid([0, 0], [0, 1], max_level, win, with_gradients=False)
+            gen = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=max_level), want_iters=True)[0]
+        monkeypatch.delenv("FT_LK_FIXED_WINDOWS")
+        for a, b in zip(out, gen):
+            assert np.array_equal(a, b)
 
 
 def test_lk_initial_guess_no_initial_flow_and_min_eig(dev, lk_form):
