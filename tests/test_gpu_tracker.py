@@ -177,6 +177,44 @@ def test_pipelined_groups_with_lookahead_equal_plain_feed():
             assert np.array_equal(tr_a[k][0], tr_b[k][0]) and np.array_equal(tr_a[k][1], tr_b[k][1])
 
 
+def test_large_stream_fed_pipelined_equals_plain_feed(monkeypatch):
+    """One stream of 2 000 features fed pipelined runs its next frame's ingest, pyramids and detector on a device queue
+    of their own, beside the tracking (forward and backward pass in one launch).  Counts, points and feature database
+    equal the plain feed's, with that queue and (FT_FRONT_QUEUE=0) without it."""
+    w, h, n_frames = 1280, 720, 8
+    q = synth.Sequence(w, h, n_frames, stream_id=31, scene="blobs")
+    opts = dict(num_pts=2000, win_size=21, pyr_levels=4, forward_backward=1, fb_thresh=1.0, grid_x=9, grid_y=5, use_gyro_seed=1)
+
+    def run(pipelined):
+        b = tracker.BatchTracker(1, w, h, **opts)
+        b.set_calibration(0, q.calib8, q.T_cam_imu)
+        for t, g, a in zip(q.imu_t, q.gyro, q.accel):
+            b.feed_imu(0, t, a, g)
+        tracked = attempted = 0
+        for i in range(n_frames):
+            tr, at = b.feed_host([q.timestamps[i]], [q.frames[i]], pipelined=pipelined)
+            tracked += tr
+            attempted += at
+        if pipelined:
+            tr, at = b.flush()
+            tracked += tr
+            attempted += at
+        return tracked, attempted, b.points(0), b.database_size(0), _tracks(b, 0)
+
+    plain = run(False)
+    piped = run(True)
+    monkeypatch.setenv("FT_FRONT_QUEUE", "0")
+    one_queue = run(True)
+    monkeypatch.delenv("FT_FRONT_QUEUE")
+    assert plain[0] > 10000 and plain[1] >= 1900 * (n_frames - 1)
+    for other in (piped, one_queue):
+        assert other[0] == plain[0] and other[1] == plain[1] and other[3] == plain[3]
+        assert np.array_equal(other[2][0], plain[2][0]) and np.array_equal(other[2][1], plain[2][1])
+        assert other[4].keys() == plain[4].keys()
+        for k in plain[4]:
+            assert np.array_equal(other[4][k][0], plain[4][k][0]) and np.array_equal(other[4][k][1], plain[4][k][1])
+
+
 def test_late_detector_with_streams_that_lose_tracking():
     """One-set-at-a-time feeds queue the detector after the tracking launch and collect it at the next feed; a stream
     that lost everything (blank frames) needs the detection of its new frame at once.  Must equal the CPU checker fed
