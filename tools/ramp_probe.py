@@ -47,8 +47,9 @@ f = bench.Feeder(tracker, wl, seqs, dev_frames, 0, 0, 0, False)
 f.run(0, 1)
 torch.cuda.synchronize()
 t0 = time.perf_counter(); marks = []
-for i in range(1, 121):
+n3 = min(120, K)   # the sequences hold K + 1 frames
+for i in range(1, n3 + 1):
     f.feed(i); marks.append(time.perf_counter() - t0)
 f.b.flush()
 m = np.array(marks)
-print("warm process, new tracker, pipelined: us per step over steps", " ".join(f"{a}-{a+10}:{(m[a+9]-(m[a-1] if a else 0))/10*1e6:.0f}" for a in range(0, 120, 10)))
+print("warm process, new tracker, pipelined: us per step over steps", " ".join(f"{a}-{a+10}:{(m[a+9]-(m[a-1] if a else 0))/10*1e6:.0f}" for a in range(0, n3 - 9, 10)))
