@@ -144,7 +144,12 @@ __global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, Fram
                 }
                 uint8_t* drow = gdst + (size_t)gy * gpitch + (size_t)gx0 * 4;
                 if (gx0 + 3 < w) {
-                    *reinterpret_cast<uint4*>(drow) = make_uint4(o[0], o[1], o[2], o[3]);
+                    // written once and not read again by this launch or the next ones of a frame set: a streaming store
+                    // keeps the 4 bytes per pixel out of the caches (64 x 1280x720: 4.3 -> 6.2 TB/s; level 0 written
+                    // that way instead made the kernels that read it next slower)
+                    typedef uint32_t lv_u4 __attribute__((ext_vector_type(4)));
+                    lv_u4 v4 = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(v4, reinterpret_cast<lv_u4*>(drow));
                 } else {
                     for (int c = 0; c < 4 && gx0 + c < w; c++) reinterpret_cast<uint32_t*>(drow)[c] = o[c];
                 }
