@@ -119,6 +119,8 @@ struct ft_ctx {
 
     // LK staging
     uint8_t* lk_in_host = nullptr;  uint8_t* lk_in_dev = nullptr;  size_t lk_in_bytes = 0;
+    bool lk_in_bar = false;         // lk_in_dev is written by the host through the bus window (see ft_ctx_create) ...
+    int lk_bar_max = 4096;          // ... for batches of up to this many points (FT_LK_BAR_MAX)
     uint8_t* lk_in_host_dev = nullptr;    // device-side address of lk_in_host
     uint8_t* lk_out_host = nullptr; uint8_t* lk_out_dev = nullptr; size_t lk_out_bytes = 0;
     uint8_t* lk_out_host_dev = nullptr;   // device-side address of lk_out_host
@@ -540,7 +542,22 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
         if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) return fail(FT_E_HIP);
         c->lk_in_host_dev = (uint8_t*)dp;
     }
-    if (hipMalloc(&p, c->lk_in_bytes) != hipSuccess) return fail(FT_E_NOMEM);
+    // The device copy of a tracking batch's input block.  Where the host reaches device memory through the bus window
+    // (large BAR), the block is fine-grained device memory and the host writes it there itself (write-combined, 40 KB in
+    // about 1.3 us): no kernel has to fetch it from pinned memory before the tracking launch.  FT_LK_BAR_INPUT=0: the
+    // fetch kernel as before.
+    {
+        int large_bar = 0;
+        (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device);
+        const char* e = getenv("FT_LK_BAR_INPUT");
+        c->lk_in_bar = large_bar == 1 && !(e && atoi(e) == 0);
+        if (const char* m = getenv("FT_LK_BAR_MAX")) c->lk_bar_max = atoi(m);
+    }
+    if (c->lk_in_bar) {
+        if (hipExtMallocWithFlags(&p, c->lk_in_bytes, hipDeviceMallocFinegrained) != hipSuccess) return fail(FT_E_NOMEM);
+    } else {
+        if (hipMalloc(&p, c->lk_in_bytes) != hipSuccess) return fail(FT_E_NOMEM);
+    }
     c->lk_in_dev = (uint8_t*)p;
     if (hipHostMalloc(&p, c->lk_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_out_host = (uint8_t*)p;
@@ -918,12 +935,22 @@ int ft_lk_track_async(ft_ctx* c, int n_jobs, const ft_lk_job* jobs, const ft_lk_
     // behind the tracking, the tracking wavefronts leave device copies of the job records and the template points for
     // it (its workgroups reading them over the bus as well cost more than the launch saved: single-stream latency 77
     // -> 83 us, 8 streams 16.9 -> 16.3 M features/s).
-    const bool direct_in = N <= (size_t)c->lk_direct_max && !stereo;
+    // Where the host writes the device copy itself, batches of up to lk_bar_max points take that way (64 streams in four
+    // groups 75.0 -> 77.1 M features/s, single-stream p50 79.0 -> 75.8 us; a batch of 9 700 points is better off with the
+    // fetch kernel: its 100 KB cost the host more than the launch, 39.1 -> 36.5 M).
+    const bool bar_in = c->lk_in_bar && N <= (size_t)c->lk_bar_max;
+    const bool direct_in = !bar_in && N <= (size_t)c->lk_direct_max && !stereo;
     const bool echo = direct_in && reject;
     const uint8_t* ib = direct_in ? c->lk_in_host_dev : c->lk_in_dev;
-    if (!direct_in) {
-        // (every job seeded by its homography: the kernel never looks at the guesses, and they stay behind)
-        const int n16 = (int)(((need_guess ? off_next : off_prev) + 8 * N + 15) / 16);
+    // (every job seeded by its homography: the kernel never looks at the guesses, and they stay behind)
+    const size_t in_bytes = (need_guess ? off_next : off_prev) + 8 * N;
+    if (bar_in) {
+        // nothing on the device reads the block any more (the previous batch was delivered above); the stores leave the
+        // write-combining buffers before the launch's doorbell goes out
+        memcpy(c->lk_in_dev, hb, in_bytes);
+        __builtin_ia32_sfence();
+    } else if (!direct_in) {
+        const int n16 = (int)((in_bytes + 15) / 16);
         hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, enq(c), reinterpret_cast<const uint4*>(c->lk_in_host_dev),
                            reinterpret_cast<uint4*>(c->lk_in_dev), n16);
     }
@@ -1061,9 +1088,14 @@ int ft_reject_outliers_async(ft_ctx* c, int n_sets, const ft_match_set* sets, in
         }
         off += (size_t)S.n;
     }
-    const int n16 = (int)((off_next + 8 * N + 15) / 16);
-    hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, enq(c), reinterpret_cast<const uint4*>(c->lk_in_host_dev),
-                       reinterpret_cast<uint4*>(c->lk_in_dev), n16);
+    if (c->lk_in_bar && N <= (size_t)c->lk_bar_max) {
+        memcpy(c->lk_in_dev, hb, off_next + 8 * N);
+        __builtin_ia32_sfence();
+    } else {
+        const int n16 = (int)((off_next + 8 * N + 15) / 16);
+        hipLaunchKernelGGL(fetch_block_kernel, dim3((n16 + 255) / 256), dim3(256), 0, enq(c), reinterpret_cast<const uint4*>(c->lk_in_host_dev),
+                           reinterpret_cast<uint4*>(c->lk_in_dev), n16);
+    }
     OutlierArgs o;
     o.jobs = reinterpret_cast<const LKJobDev*>(c->lk_in_dev);
     o.prev_xy = reinterpret_cast<const float*>(c->lk_in_dev + off_prev);

@@ -576,6 +576,38 @@ def test_lk_with_outlier_rejection_equals_lk_then_oracle_rejection(dev, lk_form)
     assert np.array_equal(strict[1], want)
 
 
+@pytest.mark.parametrize("n", [300, 3000])
+def test_lk_input_block_paths_agree(dev, n, monkeypatch):
+    """A tracking batch's input block reaches the device in one of three ways: written by the host straight into device
+    memory (where the device has a large BAR: the default there), read in place from pinned memory by the tracking
+    wavefronts, which leave device copies for the rejection kernel (small batches without the BAR), or fetched by a kernel.
+    Positions, status after rejection and residuals are the same."""
+    w, h = 640, 360
+    prev, nxt = synth.shifted_pair(w, h, dx=3, dy=-2, seed=77)
+    pts = synth.random_points(w, h, n, seed=78, border=10)
+    calib = np.array([420.0, 418.0, 318.0, 182.0, -0.28, 0.07, 2e-4, 1e-5])
+    prm = dev.LKParams(21, 3, flags=dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_REJECT_OUTLIERS, ransac_hypotheses=64, ransac_seed=3)
+
+    def run():
+        with _ctx(dev, w, h) as ctx:
+            ctx.upload(0, 0, prev)
+            ctx.upload(0, 1, nxt)
+            ctx.build_pyramid([0, 0], [0, 1], 3, 21, with_gradients=False)
+            return ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts, calib_prev=calib, calib_next=calib)], prm)[0]
+
+    default = run()
+    monkeypatch.setenv("FT_LK_BAR_INPUT", "0")
+    in_place_or_fetched = run()
+    monkeypatch.setenv("FT_LK_DIRECT_MAX", "0")
+    fetched = run()
+    monkeypatch.delenv("FT_LK_DIRECT_MAX")
+    monkeypatch.delenv("FT_LK_BAR_INPUT")
+    assert default[1].sum() > 0.8 * n
+    for other in (in_place_or_fetched, fetched):
+        for a, b in zip(default[:3], other[:3]):
+            assert np.array_equal(a, b)
+
+
 STEREO_RIGS = [
     # undistorted twin cameras, pure sideways baseline: the epipolar lines are the image rows
     ((460.0, 460.0, 320.0, 200.0, 0, 0, 0, 0), (460.0, 460.0, 320.0, 200.0, 0, 0, 0, 0), (0, 0, 0), (-0.11, 0, 0)),
