@@ -108,11 +108,13 @@ def test_ingest_pyramid_single_pass_bit_exact(dev, shape, win, max_level, pad):
                 assert np.array_equal(ctx.download_level(i, 1 - i, l), ref.level(l)), f"image {i} level {l}"
 
 
-@pytest.mark.parametrize("w,h,n", [(751, 479, 3), (752, 480, 8)])
-def test_staged_host_frames_pyramid_bit_exact(dev, w, h, n):
-    """Host frames through the pinned staging: a few frames (or a width that is no multiple of 16) are read in place by
-    the fused level-0 pass, many frames cross the bus in a linear pass of their own first; later rounds reuse the
-    staging buffers (the staging call waits for the pass that still reads them)."""
+@pytest.mark.parametrize("w,h,n,stage_bar", [(751, 479, 3, "1"), (751, 479, 3, "0"), (752, 480, 8, "1"), (752, 480, 2, "1"), (752, 480, 2, "0")])
+def test_staged_host_frames_pyramid_bit_exact(dev, w, h, n, stage_bar, monkeypatch):
+    """Host frames through the staging buffers.  Pinned staging: a few frames (or a width that is no multiple of 16) are read
+    in place by the fused level-0 pass, many frames cross the bus in a linear pass of their own first.  Contexts of up to
+    four streams on a device with a large BAR stage in device memory instead (FT_STAGE_BAR=0 keeps them on pinned
+    staging).  Later rounds reuse the staging buffers (the staging call waits for the pass that still reads them)."""
+    monkeypatch.setenv("FT_STAGE_BAR", stage_bar)
     with _ctx(dev, 752, 480, n_streams=n) as ctx:
         for rnd in range(3):
             frames = [synth.texture(w, h, seed=200 + n * rnd + i) for i in range(n)]
