@@ -538,8 +538,8 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
         (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device);
         const char* e = getenv("FT_STAGE_BAR");
         if (large_bar == 1 && lim->n_streams <= 4 && !(e && atoi(e) == 0)) {
-            if (hipExtMallocWithFlags(&p, c->stage_bytes_per_slot * n_slots_total, hipDeviceMallocFinegrained) != hipSuccess) return fail(FT_E_NOMEM);
-            c->stage_bar = (uint8_t*)p;
+            if (hipExtMallocWithFlags(&p, c->stage_bytes_per_slot * n_slots_total, hipDeviceMallocFinegrained) == hipSuccess) c->stage_bar = (uint8_t*)p;
+            else (void)hipGetLastError();   // pinned staging only
         }
     }
     if (hipMalloc(&p, (size_t)lim->max_width * lim->max_height * lim->n_streams) != hipSuccess) return fail(FT_E_NOMEM);
@@ -574,11 +574,11 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
         c->lk_in_bar = large_bar == 1 && !(e && atoi(e) == 0);
         if (const char* m = getenv("FT_LK_BAR_MAX")) c->lk_bar_max = atoi(m);
     }
-    if (c->lk_in_bar) {
-        if (hipExtMallocWithFlags(&p, c->lk_in_bytes, hipDeviceMallocFinegrained) != hipSuccess) return fail(FT_E_NOMEM);
-    } else {
-        if (hipMalloc(&p, c->lk_in_bytes) != hipSuccess) return fail(FT_E_NOMEM);
+    if (c->lk_in_bar && hipExtMallocWithFlags(&p, c->lk_in_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        c->lk_in_bar = false;   // no such memory here: the fetch kernel as before
     }
+    if (!c->lk_in_bar && hipMalloc(&p, c->lk_in_bytes) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_in_dev = (uint8_t*)p;
     if (hipHostMalloc(&p, c->lk_out_bytes, hipHostMallocDefault) != hipSuccess) return fail(FT_E_NOMEM);
     c->lk_out_host = (uint8_t*)p;
