@@ -19,6 +19,7 @@
 #include "ft_common.hpp"
 #include "ft_kernels_brief.hpp"
 #include "ft_kernels_fast.hpp"
+#include "ft_kernels_front.hpp"
 #include "ft_kernels_lk.hpp"
 #include "ft_kernels_match.hpp"
 #include "ft_kernels_outlier.hpp"
@@ -160,6 +161,15 @@ struct ft_ctx {
 
     // timing
     int profile = 0;   // bit 0: time kernel groups with events, bit 1: count LK work (iteration counters)
+    // pyrDown steps of a frame set that are still to be launched (levels done_to .. top): ft_fast_grid_async on the same
+    // images right after the pyramid call launches them together with the detector (ft_kernels_front.hpp); anything else
+    // that is put on the queue, or waits for it, launches them first (enq, fences, syncs).  FT_FRONT_FUSE=0: never deferred.
+    struct DeferredLevels {
+        bool active = false, busy = false;
+        ImgList L;
+        int w = 0, h = 0, top = 0, done_to = 0;
+    } deferred;
+    bool front_fuse = true;
     int lk_direct_max = 1024; // points per tracking launch up to which the input block is read in place from pinned memory (FT_LK_DIRECT_MAX)
     bool lk_fixed_windows = true;   // kernels compiled for 21 x 21 and 15 x 15 windows (FT_LK_FIXED_WINDOWS=0: the general ones)
     bool lk_fused_fb = true;  // forward-backward tracking in one launch (FT_LK_FUSED_FB=0: two launches)
@@ -176,7 +186,9 @@ struct ft_ctx {
 namespace {
 
 // the context's queue, for putting work on it: whatever is enqueued next is then the newest work on the queue
+void flush_deferred(ft_ctx* c);
 inline hipStream_t enq(ft_ctx* c) {
+    if (c->deferred.active && !c->deferred.busy) flush_deferred(c);
     c->tail_flag_seq = 0;
     if (c->cur_ != c->q_) return c->cur_;
     if (c->front_dirty_) {   // everything put on the main queue from here on comes after the front queue's work so far
@@ -327,6 +339,7 @@ int deliver_pending(ft_ctx* c, uint64_t upto) {
 }
 
 int sync_and_deliver(ft_ctx* c) {
+    if (c->deferred.active) flush_deferred(c);
     if (c->front_q_) FT_HIP(c, hipStreamSynchronize(c->front_q_));   // (also when called from inside a FrontScope)
     FT_HIP(c, hipStreamSynchronize(c->q_));
     c->tail_flag_seq = 0;
@@ -407,6 +420,15 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
     if (timed) prof_end(c, ep);
     FT_HIP(c, hipGetLastError());
     return FT_OK;
+}
+
+void flush_deferred(ft_ctx* c) {
+    ft_ctx::DeferredLevels& D = c->deferred;
+    if (!D.active || D.busy) return;
+    D.busy = true;
+    D.active = false;
+    (void)run_levels(c, D.L, D.w, D.h, D.top, true, false, D.done_to, false);
+    D.busy = false;
 }
 
 // copy a frame into the pinned staging buffer of a slot, tightly packed, once nothing on the device reads that buffer any more
@@ -497,6 +519,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lim = *lim;
     if (const char* e = getenv("FT_LK_PAIR_MAX")) c->lk_pair_max = atoi(e);
     if (const char* e = getenv("FT_LK_DIRECT_MAX")) c->lk_direct_max = atoi(e);
+    if (const char* e = getenv("FT_FRONT_FUSE")) c->front_fuse = atoi(e) != 0;
     if (const char* e = getenv("FT_LK_FIXED_WINDOWS")) c->lk_fixed_windows = atoi(e) != 0;
     if (const char* e = getenv("FT_LK_FUSED_FB")) c->lk_fused_fb = atoi(e) != 0;
     auto fail = [&](int code) { ft_ctx_destroy(c); return code; };
@@ -647,6 +670,7 @@ void ft_ctx_destroy(ft_ctx* c) {
     if (c->front_q_) { (void)hipStreamSynchronize(c->front_q_); (void)hipStreamDestroy(c->front_q_); c->front_q_ = nullptr; }
     if (c->front_ev_) (void)hipEventDestroy(c->front_ev_);
     c->cur_ = c->q_; c->front_dirty_ = false;
+    c->deferred.active = false;
     if (enq(c)) (void)hipStreamSynchronize(enq(c));
     for (auto& e : c->stage_done) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->stage_batch_ev) if (e) (void)hipEventDestroy(e);
@@ -763,8 +787,15 @@ static int frames_to_pyramid(ft_ctx* c, const ImgList& L, int n, const uint8_t* 
     }
     FT_HIP(c, hipGetLastError());
     if (top > 1) {
-        const int rc = run_levels(c, L, w, h, top, true, false, 1, false);
-        if (rc) return rc;
+        if (c->front_fuse && !(c->profile & 1) && !c->front_enabled && n <= FRAME_PTRS) {
+            // the detector call that usually follows takes these steps into its launches; anything else launches them first
+            ft_ctx::DeferredLevels& D = c->deferred;
+            D.L = L; D.w = w; D.h = h; D.top = top; D.done_to = 1;
+            D.active = true;
+        } else {
+            const int rc = run_levels(c, L, w, h, top, true, false, 1, false);
+            if (rc) return rc;
+        }
     }
     prof_end(c, ep);   // one timed group: ingest + every level
     for (int i = 0; i < n; i++) {
@@ -1194,12 +1225,36 @@ int ft_fast_grid_async(ft_ctx* c, int n, const int* streams, const int* slots, i
     ft_keypoint* kp_dev = reinterpret_cast<ft_keypoint*>(out_block);
     int* kept_dev = reinterpret_cast<int*>(out_block + cnt_off);
     int* surv_dev = kept_dev + (size_t)n * cells;
-    EventPair ep;
-    prof_begin(c, 2, ep);
     const int tiles = fast_tiles_x(w) * fast_tiles_y(h);
-    hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(64), 0, enq(c), c->arena, L, G, c->cand, c->cand_count);
-    hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
-    prof_end(c, ep);
+    // pyrDown steps of these very images that are still to be launched ride along with the detector and the ranking
+    ft_ctx::DeferredLevels& D = c->deferred;
+    bool fuse = D.active && !D.busy && D.L.n == n && D.w == w && D.h == h && D.done_to == 1 && D.top >= 2;
+    for (int i = 0; i < n && fuse; i++) fuse = D.L.idx[i] == L.idx[i];
+    if (fuse) {
+        D.active = false;
+        D.busy = true;   // (enq() below must not look at the record again)
+        const int w1 = (w + 1) / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
+        const int lb1 = xcd_grid(((w1 + LV_TX - 1) / LV_TX) * ((h1 + LV_TY - 1) / LV_TY) * n);
+        hipLaunchKernelGGL(front_detect_level_kernel, dim3(lb1 + xcd_grid((tiles * n + 3) / 4)), dim3(256), 0, enq(c), c->arena, L, G, c->cand, c->cand_count, 1, w1,
+                           h1, lb1);
+        int done_to = 2;
+        if (D.top >= 3) {
+            const int lb2 = xcd_grid(((w2 + LV_TX - 1) / LV_TX) * ((h2 + LV_TY - 1) / LV_TY) * n);
+            hipLaunchKernelGGL(front_topk_level_kernel, dim3(lb2 + (n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev,
+                               n * cells, c->arena, L, 2, w2, h2, lb2);
+            done_to = 3;
+        } else {
+            hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
+        }
+        if (D.top > done_to) (void)run_levels(c, L, w, h, D.top, true, false, done_to, false);
+        D.busy = false;
+    } else {
+        EventPair ep;
+        prof_begin(c, 2, ep);
+        hipLaunchKernelGGL(fast_detect_kernel, dim3(xcd_grid(tiles * n)), dim3(64), 0, enq(c), c->arena, L, G, c->cand, c->cand_count);
+        hipLaunchKernelGGL(fast_topk_kernel, dim3((n * cells + 3) / 4), dim3(256), 0, enq(c), G, c->cand, c->cand_count, kp_dev, kept_dev, surv_dev, n * cells);
+        prof_end(c, ep);
+    }
     FT_HIP(c, hipGetLastError());
     // cand is indexed [image*cells + cell][cand_cap], the keypoints [image*cells + cell][per_cell]
     PendingFast& F = c->fast_pending[ring];
@@ -1378,6 +1433,14 @@ int ft_sync(ft_ctx* c) {
     return sync_and_deliver(c);
 }
 
+int ft_flush(ft_ctx* c) {
+    if (!c) return FT_E_INVALID;
+    FT_HIP(c, hipSetDevice(c->device));
+    if (c->deferred.active) flush_deferred(c);
+    FT_HIP(c, hipGetLastError());
+    return FT_OK;
+}
+
 int ft_set_front_queue(ft_ctx* c, int on) {
     if (!c) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
@@ -1393,6 +1456,7 @@ int ft_set_front_queue(ft_ctx* c, int on) {
 int ft_fence(ft_ctx* c, uint64_t* token) {
     if (!c || !token) return FT_E_INVALID;
     FT_HIP(c, hipSetDevice(c->device));
+    if (c->deferred.active) flush_deferred(c);
     if (c->front_dirty_) (void)enq(c);   // the fence covers the front queue's work as well
     const uint64_t id = ++c->fence_ids;
     ft_ctx::Fence& f = c->fences[id % ft_ctx::FENCE_RING];

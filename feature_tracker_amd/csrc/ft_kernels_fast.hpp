@@ -12,6 +12,8 @@
 //   fast_topk_kernel   : one wavefront per cell extracts the first `per_cell` candidates in the total order
 //                        (score desc, y asc, x asc).
 #pragma once
+#include <cstddef>
+
 #include "ft_common.hpp"
 
 namespace ftd {
@@ -116,17 +118,25 @@ __device__ __forceinline__ int fd_wave_scan(int v) {
 // Fused detector: the pixel tile is staged in LDS once; a cheap compass test on four pixels per lane compacts the
 // candidates; the exact corner strength is evaluated only for those (dense lanes); strict 3x3 maxima of the LDS score
 // tile go straight to the per-cell candidate lists.  No score map in HBM.
-__global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L, FastGrid G, uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
-    __shared__ __attribute__((aligned(16))) uint8_t pix[FD_PROWS * FD_PPITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[FD_CH * FD_CW];
-    __shared__ uint16_t list[FD_LIST];
-    __shared__ __attribute__((aligned(4))) uint8_t col_ok[FD_CW];   // column lies in the inset of some cell
-    __shared__ uint8_t row_ok[FD_CH];                               // row lies in the inset of some cell
-    const int lane = threadIdx.x;
-    // work list: (image, tile row, tile column), images outermost
+// LDS of one detector wavefront (the wavefronts of a workgroup share nothing)
+struct __attribute__((aligned(16))) FastTileLds {
+    uint8_t pix[FD_PROWS * FD_PPITCH];
+    uint8_t sc[FD_CH * FD_CW];
+    uint16_t list[FD_LIST];
+    uint8_t col_ok[FD_CW];   // column lies in the inset of some cell
+    uint8_t row_ok[FD_CH];   // row lies in the inset of some cell
+};
+static_assert(offsetof(FastTileLds, sc) % 16 == 0 && offsetof(FastTileLds, list) % 16 == 0 && offsetof(FastTileLds, col_ok) % 4 == 0, "LDS alignment of the detector tile");
+
+// one tile (work item `item` of the list (image, tile row, tile column), images outermost) on one wavefront
+__device__ __forceinline__ void fast_detect_tile(const ArenaDesc& A, const ImgList& L, const FastGrid& G, uint32_t* __restrict__ cand,
+                                                 int* __restrict__ cand_count, int item, int lane, FastTileLds& T) {
+    uint8_t* const pix = T.pix;
+    uint8_t* const sc = T.sc;
+    uint16_t* const list = T.list;
+    uint8_t* const col_ok = T.col_ok;
+    uint8_t* const row_ok = T.row_ok;
     const int tiles_x = fast_tiles_x(G.w), tiles_y = fast_tiles_y(G.h);
-    const int item = xcd_item(blockIdx.x, tiles_x * tiles_y * L.n);
-    if (item >= tiles_x * tiles_y * L.n) return;
     const int img_i = item / (tiles_x * tiles_y), tile_i = item - img_i * (tiles_x * tiles_y);
     const int slot = L.idx[img_i];
     const int CX0 = (tile_i % tiles_x) * FD_OW, OY = (tile_i / tiles_x) * FD_OH;
@@ -309,6 +319,14 @@ __global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L,
     }
 }
 
+__global__ void __launch_bounds__(64) fast_detect_kernel(ArenaDesc A, ImgList L, FastGrid G, uint32_t* __restrict__ cand, int* __restrict__ cand_count) {
+    __shared__ FastTileLds T;
+    const int total = fast_tiles_x(G.w) * fast_tiles_y(G.h) * L.n;
+    const int item = xcd_item(blockIdx.x, total);
+    if (item >= total) return;
+    fast_detect_tile(A, L, G, cand, cand_count, item, threadIdx.x, T);
+}
+
 // wave-wide maximum (result uniform in all lanes): four DPP stages inside the rows of 16 lanes, two across rows
 __device__ __forceinline__ uint32_t fast_wave_max(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
@@ -324,12 +342,8 @@ __device__ __forceinline__ uint32_t fast_wave_max(uint32_t v) {
 // first 256 candidates of the cell in registers (a cell rarely has more than a few dozen NMS survivors).  Also
 // reports the number of NMS survivors of the cell and leaves its candidate counter at zero for the next detector pass.
 constexpr int FT_TOPK_REGS = 4;
-__global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32_t* __restrict__ cand, int* __restrict__ cand_count,
-                                                       ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count,
-                                                       int total_cells) {
-    const int lane = threadIdx.x & 63;
-    const int gcell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gcell >= total_cells) return;          // uniform for the wave
+__device__ __forceinline__ void fast_topk_cell(const FastGrid& G, const uint32_t* __restrict__ cand, int* __restrict__ cand_count,
+                                               ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count, int gcell, int lane) {
     const int cell = gcell % (G.ct_cols * G.ct_rows);
     const int survivors = cand_count[(size_t)gcell * FAST_COUNT_STRIDE];
     const int n = min(survivors, G.cand_cap);
@@ -363,6 +377,13 @@ __global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32
         surv_count[gcell] = survivors;
         cand_count[(size_t)gcell * FAST_COUNT_STRIDE] = 0;
     }
+}
+__global__ void __launch_bounds__(256) fast_topk_kernel(FastGrid G, const uint32_t* __restrict__ cand, int* __restrict__ cand_count,
+                                                       ft_keypoint* __restrict__ out, int* __restrict__ out_count, int* __restrict__ surv_count,
+                                                       int total_cells) {
+    const int gcell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gcell >= total_cells) return;          // uniform for the wave
+    fast_topk_cell(G, cand, cand_count, out, out_count, surv_count, gcell, threadIdx.x & 63);
 }
 
 }  // namespace ftd

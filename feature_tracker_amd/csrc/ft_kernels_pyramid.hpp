@@ -30,21 +30,17 @@ struct FramePtrs {
 struct __attribute__((packed)) U2Unaligned { uint32_t a, b; };
 
 // FROM_FRAME: the source is frame F.p[i] (row stride sstride, any alignment) and the tile is also written to level 0
+// one tile (work item `item` of the list (image, tile row, tile column), images outermost) on one 256-thread workgroup;
+// tile: LV_LDS_ROWS * LV_LDS_PITCH bytes of LDS, 16-byte aligned
 template <bool FROM_FRAME>
-__global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, FramePtrs F, int first, int level, int w, int h, uint64_t sstride,
-                                                    int do_grad, int do_down) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[LV_LDS_ROWS * LV_LDS_PITCH];
-    // work list: (image, tile row, tile column), images outermost
+__device__ __forceinline__ void level_tile(const ArenaDesc& A, const ImgList& L, const FramePtrs& F, int first, int level, int w, int h, uint64_t sstride,
+                                           int do_grad, int do_down, int item, int t, uint8_t* __restrict__ tile) {
     const int tiles_x = (w + LV_TX - 1) / LV_TX, tiles_y = (h + LV_TY - 1) / LV_TY;
-    const int n_img = FROM_FRAME ? min(FRAME_PTRS, L.n - first) : L.n;
-    const int item = xcd_item(blockIdx.x, tiles_x * tiles_y * n_img);
-    if (item >= tiles_x * tiles_y * n_img) return;
     const int img_i = item / (tiles_x * tiles_y), tile_i = item - img_i * (tiles_x * tiles_y);
     const int slot = L.idx[first + img_i];
     const uint8_t* __restrict__ src = FROM_FRAME ? F.p[img_i] : level_img(A, slot, level);
     const uint64_t spitch = FROM_FRAME ? sstride : (uint64_t)A.lv[level].img_pitch;
     const int X0 = (tile_i % tiles_x) * LV_TX, Y0 = (tile_i / tiles_x) * LV_TY;
-    const int t = threadIdx.x;
 
     // ---- stage the tile: a wavefront load covers 3 rows x 18 groups of 8 bytes; 3 rounds x 4 waves = 36 rows.
     //      Only groups that lie completely inside the image row are loaded here. ----
@@ -191,6 +187,17 @@ __global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, Fram
             }
         }
     }
+}
+
+template <bool FROM_FRAME>
+__global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, FramePtrs F, int first, int level, int w, int h, uint64_t sstride,
+                                                    int do_grad, int do_down) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[LV_LDS_ROWS * LV_LDS_PITCH];
+    const int tiles = ((w + LV_TX - 1) / LV_TX) * ((h + LV_TY - 1) / LV_TY);
+    const int n_img = FROM_FRAME ? min(FRAME_PTRS, L.n - first) : L.n;
+    const int item = xcd_item(blockIdx.x, tiles * n_img);
+    if (item >= tiles * n_img) return;
+    level_tile<FROM_FRAME>(A, L, F, first, level, w, h, sstride, do_grad, do_down, item, threadIdx.x, tile);
 }
 
 // ---- batched frame ingest: n device-resident frames -> level 0 of their slots, one launch ----

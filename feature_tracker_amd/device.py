@@ -69,7 +69,7 @@ class ft_kernel_time(C.Structure):
 SYMBOLS = ["ft_ctx_create", "ft_ctx_destroy", "ft_upload", "ft_set_frame_device", "ft_set_frames_device",
            "ft_set_frames_device_pyramid", "ft_build_pyramid",
            "ft_build_gradients", "ft_lk_track", "ft_lk_track_async", "ft_reject_outliers", "ft_reject_outliers_async", "ft_match_descriptors", "ft_compute_descriptors", "ft_stage_frame", "ft_set_frames_staged_pyramid", "ft_fast_grid", "ft_fast_grid_async",
-           "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait", "ft_set_front_queue",
+           "ft_homography", "ft_predict_flow", "ft_level_info", "ft_download_level", "ft_download_grad", "ft_sync", "ft_fence", "ft_wait", "ft_set_front_queue", "ft_flush",
            "ft_profile", "ft_kernel_times", "ft_queue_time_begin", "ft_queue_time_end", "ft_strerror",
            "ft_last_hip_error", "ft_device_count"]
 
@@ -134,6 +134,7 @@ def load_library():
     lib.ft_fence.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.ft_wait.argtypes = [vp, C.c_uint64]
     lib.ft_set_front_queue.argtypes = [vp, C.c_int]
+    lib.ft_flush.argtypes = [vp]
     lib.ft_profile.argtypes = [vp, C.c_int]
     lib.ft_kernel_times.argtypes = [vp, C.POINTER(ft_kernel_time), C.c_int]
     lib.ft_queue_time_begin.argtypes = [vp]
@@ -410,6 +411,10 @@ class DeviceContext:
     def set_front_queue(self, on):
         """Ingest, pyramids and detector on a device queue of their own, beside the tracking work (see ft_device.h)."""
         self._check(self.lib.ft_set_front_queue(self._ctx, 1 if on else 0), "ft_set_front_queue")
+
+    def flush(self):
+        """Launch the pyramid steps the library holds back for a detector call that may follow (see ft_device.h)."""
+        self._check(self.lib.ft_flush(self._ctx), "ft_flush")
 
     def profile(self, enable):
         self._check(self.lib.ft_profile(self._ctx, int(enable)), "ft_profile")

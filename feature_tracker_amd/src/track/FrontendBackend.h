@@ -41,6 +41,8 @@ public:
     // run ingest, pyramids and detector on a device queue of their own, beside the tracking work (a backend without
     // queues has nothing to do)
     virtual int set_front_queue(bool) { return FT_OK; }
+    // launch what the backend holds back in the hope of a detector call (a backend that holds nothing back has nothing to do)
+    virtual int flush() { return FT_OK; }
     virtual const char* name() const = 0;
 };
 

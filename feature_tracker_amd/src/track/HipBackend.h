@@ -59,6 +59,7 @@ public:
     int fence(uint64_t* token) override { return ft_fence(ctx_, token); }
     int wait(uint64_t token) override { return ft_wait(ctx_, token); }
     int set_front_queue(bool on) override { return ft_set_front_queue(ctx_, on ? 1 : 0); }
+    int flush() override { return ft_flush(ctx_); }
     const char* name() const override { return "hip-gfx950"; }
     ft_ctx* ctx() { return ctx_; }
 

@@ -269,6 +269,7 @@ int TrackKLT::feed_monocular(double timestamp, const Image8& img, size_t cam_id)
     const int stream_cur = stream0 + (int)cam_id, slot_cur = next_slot(cam_id);
     if ((rc = be->stage_frame(stream_cur, slot_cur, img.data, img.cols, img.rows, img.step)) != FT_OK) return rc;
     if ((rc = be->set_frames_staged_pyramid(1, &stream_cur, &slot_cur, img.cols, img.rows, pyr_levels, win_size, win_size, nullptr)) != FT_OK) return rc;
+    if ((rc = be->flush()) != FT_OK) return rc;   // no detector call rides on this pyramid: launch all of it now
     MonoPlan plan;
     mono_begin(timestamp, img.cols, img.rows, cam_id, plan);
     const ft_lk_params prm = lk_params();
@@ -502,6 +503,7 @@ int TrackKLT::feed_stereo(double timestamp, const Image8& img_leftin, const Imag
         // the previous pair's detector ran while the frames were copied
         if ((rc = promote_stereo_detection()) != FT_OK) return abort_feed(rc, cam_id_left, cam_id_right);
         if ((rc = be->set_frames_staged_pyramid(2, streams, slots, img_leftin.cols, img_leftin.rows, pyr_levels, win_size, win_size, nullptr)) != FT_OK) return rc;
+        if ((rc = be->flush()) != FT_OK) return rc;   // (the detector of this pair is queued behind its tracking)
     } else {
         if ((rc = promote_stereo_detection()) != FT_OK) return abort_feed(rc, cam_id_left, cam_id_right);
         if ((rc = be->upload(sl, cur_l, img_leftin.data, img_leftin.cols, img_leftin.rows, img_leftin.step)) != FT_OK) return rc;

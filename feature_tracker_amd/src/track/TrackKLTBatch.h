@@ -363,7 +363,7 @@ private:
         }
         D.who.clear();
         if (detect) return enqueue_detect(frames, slots, D);
-        return FT_OK;
+        return be->flush();   // no detector call follows: the pyramid's last launches must not wait for the host's next step
     }
 
     // the ranked per-cell detector of every stream's frame in the given ring slots, one batched call

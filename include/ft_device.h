@@ -257,6 +257,12 @@ int ft_wait(ft_ctx* ctx, uint64_t token);
  * time.  FT_FRONT_QUEUE=0 / 1 in the environment overrides the call.
  * No reference counterpart: the reference's OpenCV calls are synchronous. */
 int ft_set_front_queue(ft_ctx* ctx, int on);
+/* The pyramid calls that start from frames (ft_set_frames_device_pyramid, ft_set_frames_staged_pyramid) may hold back the
+ * launches of the levels above 1: an ft_fast_grid_async call on the same images right behind them carries those steps
+ * in its own launches (detector and level 1 -> 2 share one, ranking and level 2 -> 3 the next).  Any other call that puts
+ * work on the queue or waits for it launches them first, so results never depend on it; ft_flush launches them now, for
+ * a caller that will do host work before its next call (FT_FRONT_FUSE=0: nothing is ever held back). */
+int ft_flush(ft_ctx* ctx);
 
 /* Timing. ft_profile(ctx, mode): mode 1 brackets every kernel group with HIP events on the context's queue (adds a
  * little overhead; the kernels launched are exactly those of an unprofiled run); mode 2 counts the LK work instead

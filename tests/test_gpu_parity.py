@@ -321,6 +321,33 @@ def test_fast_grid_bit_exact(dev, shape, grid, need, thr):
         assert cell_counts[c] == O.fast(img[y0:y0 + sy, x0:x0 + sx], thr).shape[0]
 
 
+@pytest.mark.parametrize("shape,max_level,n", [((480, 752), 3, 3), ((479, 751), 2, 2), ((720, 1280), 4, 2), ((240, 376), 1, 2)])
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_pyramid_then_detector_in_shared_launches(dev, shape, max_level, n, fuse, monkeypatch):
+    """A detector call right behind the pyramid call of the same frames carries the pyramid's upper levels in its own
+    launches (detector + level 1 -> 2, ranking + level 2 -> 3; FT_FRONT_FUSE=0: separate launches).  Every level and the
+    ranked keypoints equal the CPU checker's; a second round with another call in between (which makes the library launch
+    what it held back) does as well."""
+    h, w = shape
+    monkeypatch.setenv("FT_FRONT_FUSE", fuse)
+    frames = [synth.texture(w, h, seed=300 + i, n_shapes=300) for i in range(2 * n)]
+    with _ctx(dev, w, h, n_streams=n, max_per_cell=16) as ctx:
+        for rnd in range(2):
+            fr = frames[rnd * n:(rnd + 1) * n]
+            ach = ctx.set_frames_host_pyramid(list(range(n)), [rnd] * n, fr, max_level=max_level, win=21)
+            if rnd == 1:
+                ctx.flush()
+            out, n_out, _ = ctx.fast_grid(list(range(n)), [rnd] * n, 20, 5, 4, 8, sync=False)
+            ctx.sync()
+            for i, f in enumerate(fr):
+                ref = O.Pyramid(f, 21, max_level)
+                assert ach[i] == ref.levels - 1
+                for l in range(ref.levels):
+                    assert np.array_equal(ctx.download_level(i, rnd, l), ref.level(l)), f"round {rnd} image {i} level {l}"
+                want = O.grid_fast(f, 8 * 20 - 1, 5, 4, 20)
+                assert np.array_equal(out[i, : n_out[i]], want)
+
+
 def test_fast_grid_batched_and_plateaus(dev):
     rng = np.random.default_rng(7)
     imgs = [synth.texture(376, 240, seed=90 + i, n_shapes=300) for i in range(3)]
