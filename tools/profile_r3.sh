@@ -11,6 +11,9 @@ one="--steps 20 --warmup 4 --repeats 1 --no-extra-legs --no-cpu-baseline --no-la
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --steps 20 --warmup 5 > $out/bench_under_rocprof.json 2> $out/trace.err
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 echo trace done
+# the one-group runs keep every kind of front work in launches of its own (FT_FRONT_FUSE=0), so that the counters of the
+# pyramid passes and of the detector stay apart; the device functions are the same as in the shared launches
+export FT_FRONT_FUSE=0
 for wl in cfg4 cfg4_win15; do
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_g1_$wl -o bench -- python3 bench.py --workload $wl $one > $out/bench_groups1_${wl}_under_rocprof.json 2> $out/trace_g1_$wl.err
   find $out/trace_g1_$wl -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_groups1_$wl.csv \;
