@@ -78,17 +78,19 @@ __device__ inline uint32_t fast_key(int score, int ly, int lx) {
 
 // Detector tile geometry.  One wavefront owns one tile and shares nothing with other wavefronts (no workgroup barrier:
 // a wavefront that waits for its pixels or for LDS is covered by the seven others of its SIMD, not held up by the
-// slowest wavefront of a workgroup).  A tile reports the corners of a 60x30 output region whose first column is 2 mod 4
-// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x32
-// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 30: exactly 16 dwords x 32 rows
-// = eight 4-pixel tasks per lane, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the radius of
+// slowest wavefront of a workgroup).  A tile reports the corners of a 60x14 output region whose first column is 2 mod 4
+// (OX = 60*bx + 2: no corner can lie in image columns 0..2, so nothing is lost).  Scores are computed for the 64x16
+// "container" around it, CX0 = OX - 2 (a multiple of 4) .. CX0 + 63, rows OY - 1 .. OY + 14: exactly 16 dwords x 16 rows
+// = four 4-pixel tasks per lane, and the 1-pixel apron the 3x3 suppression needs.  The pixel tile adds the radius of
 // the circle and is staged from column CX0 - 8 in 8-byte groups.  (Measured on 64 images of 752x480: tiles of 14 and
-// of 30 rows take the same time within 2 %; the taller tile stages 1.7 instead of 2.1 bytes per output pixel.)
-constexpr int FD_ROUNDS = 8;                     // 4 container rows per round of the 64 lanes
+// of 30 rows take the same time within 2 %, the taller tile stages 1.7 instead of 2.1 bytes per output pixel; on the 16
+// images of one stream group's launch the time is one wavefront's chain of dependent steps, and the lower tile has half
+// of it: 64 streams in four groups + 1 %, 32 streams + 2.5 %, 8 streams + 4 %.)
+constexpr int FD_ROUNDS = 4;                     // 4 container rows per round of the 64 lanes
 constexpr int FD_OW = 60, FD_OH = 4 * FD_ROUNDS - 2;    // output region
 constexpr int FD_CW = 64, FD_CH = 4 * FD_ROUNDS;        // score container
 constexpr int FD_PPITCH = 80;                    // pixel tile row: columns CX0-8 .. CX0+71
-constexpr int FD_PROWS = FD_CH + 6;              // rows OY-4 .. OY+33
+constexpr int FD_PROWS = FD_CH + 6;              // rows OY-4 .. OY+17
 constexpr int FD_GROUPS = FD_PPITCH / 8;         // 8-byte groups per pixel row
 constexpr int FD_LIST = FD_CW * FD_CH;           // candidate list capacity
 constexpr int FD_ENTRIES_AT = FD_LIST - FD_LIST / 4;   // one task entry per four pixels, kept in the list's last quarter
@@ -143,7 +145,7 @@ __device__ __forceinline__ void fast_detect_tile(const ArenaDesc& A, const ImgLi
     const uint8_t* __restrict__ img = level_img(A, slot, 0);
     const uint32_t pitch = A.lv[0].img_pitch;
 
-    // ---- stage pixels: 38 rows x 10 groups of 8 bytes = 380 loads, six per lane, all issued before the first is used.
+    // ---- stage pixels: 22 rows x 10 groups of 8 bytes = 220 loads, four per lane, all issued before the first is used.
     //      Rows are clamped into the image and the group left of the image is clamped to column 0: only insets are
     //      ever evaluated, and an inset pixel's circle lies inside the image.  No byte outside [0, w) of a row is
     //      read: a group that straddles the row end is loaded from the last 8 bytes of the row and shifted into
@@ -252,7 +254,7 @@ __device__ __forceinline__ void fast_detect_tile(const ArenaDesc& A, const ImgLi
 
     // ---- entries -> one list element per candidate pixel (dense lanes for the strength pass).  A batch of 64 entries
     //      writes at most 256 elements from 256 * batch on, which never reaches an entry that is still to be read
-    //      (the entries of batch j start at FD_ENTRIES_AT + 64 j = 1536 + 64 j). ----
+    //      (the entries of batch j start at FD_ENTRIES_AT + 64 j = 768 + 64 j, and there are four batches at most). ----
     int n_list = 0;                                                          // uniform: elements in the candidate list
     for (int base = 0; base < n_ent; base += 64) {
         const int e = base + lane < n_ent ? (int)list[FD_ENTRIES_AT + base + lane] : 0;
@@ -297,7 +299,7 @@ __device__ __forceinline__ void fast_detect_tile(const ArenaDesc& A, const ImgLi
     }
     fd_phase_fence();
 
-    // ---- strict 3x3 maxima of the output region (container rows 1..30, columns 2..61) -> per-cell candidate lists.
+    // ---- strict 3x3 maxima of the output region (container rows 1..14, columns 2..61) -> per-cell candidate lists.
     //      Only the listed corners have a score; the eight neighbours are read unconditionally so that the LDS reads of
     //      one entry are in flight together instead of forming a chain of dependent, short-circuited tests. ----
     const int cells = G.ct_cols * G.ct_rows;
