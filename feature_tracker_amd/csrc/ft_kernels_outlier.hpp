@@ -15,7 +15,8 @@
 // rounds of 32.  A hypothesis is solved by eight lanes, one per equation of the 8x9 system, each holding its row in
 // registers; pivot search and the pivot row travel by lane shuffles, so the elimination touches no memory.  The inlier
 // counts of a round's 32 models are shared by all 256 threads (32 models x 8 slices of the point set, points read from
-// LDS).  After every round one thread walks its models in index order exactly as a sequential loop would: a model with
+// LDS), eight models per counting pass.  After every pass the first wavefront walks the pass's models in index order exactly
+// as a sequential loop would (lane k holds model k's count and the hypothesis count it would leave): a model with
 // more inliers than the best so far becomes the best and lowers the number of hypotheses still to be tried to the
 // smallest N with (1 - w^8)^N <= 0.001, w = its inlier ratio (the adaptive iteration count that the confidence argument
 // 0.999 of cv::findFundamentalMat stands for; OpenCV's own count falls with w^7, because its minimal sample has seven
@@ -95,7 +96,7 @@ __device__ __forceinline__ bool ro_inlier(const double* F, float4 m, float thr2)
 }
 
 constexpr int RO_HYP_PER_WG = 32;     // hypotheses per round (8 lanes each)
-constexpr int RO_SUB = 4;             // models whose inliers are counted together (a power of two)
+constexpr int RO_SUB = 8;             // models whose inliers are counted together (a power of two)
 constexpr int RO_NORM_LDS = 1024;     // normalized points kept in LDS; the rest is read from the global copy
 constexpr int RO_MAX_HYP = 1024;      // upper bound of OutlierArgs::hypotheses
 constexpr int RO_CHUNK = 512;         // points per workgroup of a pair that is split into parts
@@ -123,12 +124,53 @@ __device__ inline bool ro_pair_barrier(unsigned* bar, unsigned target, unsigned 
 }
 
 // Hypotheses to try before a sample of eight inliers has been drawn with probability 0.999, given the best model so far
-// has `inliers` of n points: the smallest N with (1 - w^8)^N <= 0.001, at most max_h.  Plain multiplications in a fixed
-// order (no pow, no log), so the CPU checker gets the same number.
+// has `inliers` of n points: the smallest N with (1 - w^8)^N <= 0.001, at most max_h, where the power is the product
+// p_N = (...((q * q) * q)...) of plain multiplications in that order (no pow, no log), so the CPU checker gets the same
+// number.  A poor model (few inliers) makes that a walk over max_h dependent multiplications by one thread while its
+// workgroup waits, so the walk is skipped whenever its outcome is certain: p_N differs from the exact power by less
+// than N * 2^-52 relative, and so does the power by repeated squaring below; where that one clears the bound by a
+// billionth on either side of N, the walk would stop at the same N.  In the band (and only there) the walk runs.
+__device__ inline double ro_pow_int(double q, int e) {
+    double r = 1., b = q;
+    while (e) {
+        if (e & 1) r *= b;
+        b *= b;
+        e >>= 1;
+    }
+    return r;
+}
 __device__ inline int ro_hypotheses_needed(int inliers, int n, int max_h) {
     const double w = (double)inliers / (double)n;
     const double w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
     const double q = 1. - w8;
+    if (max_h <= 1) return max_h < 0 ? 0 : max_h;
+    if (q <= 0.001) return 1;                     // p_1 = q
+    {
+        const double hi = 0.001 * (1. + 1e-9), lo = 0.001 * (1. - 1e-9);
+        // about ln(0.001) / ln(q); single precision is enough for a first guess
+        const float fw8 = (float)w8;
+        const float lq = fw8 < 0.01f ? -fw8 * (1.f + 0.5f * fw8) : __logf((float)q);
+        const float est = -6.9077553f / lq;
+        int N0 = est >= (float)(max_h - 1) ? max_h - 1 : ((int)est < 1 ? 1 : (int)est);
+        double p = ro_pow_int(q, N0);
+        for (int tries = 0; tries < 6; tries++) {
+            if (p > hi) {                          // the walk goes past N0
+                if (N0 >= max_h - 1) return max_h;
+                const double pn = p * q;
+                if (pn < lo) return N0 + 1;
+                if (!(pn > hi)) break;
+                N0++; p = pn;
+            } else if (p < lo) {                   // the walk stops at N0 or before
+                if (N0 == 1) return 1;
+                const double pp = ro_pow_int(q, N0 - 1);
+                if (pp > hi) return N0;
+                if (!(pp < lo)) break;
+                N0--; p = pp;
+            } else {
+                break;
+            }
+        }
+    }
     double p = 1.;
     int N = 0;
     while (N < max_h) {
@@ -188,12 +230,17 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
             {
                 int idx[8];
                 uint32_t draw = 0;
+                const uint32_t n_inv = 0xffffffffu / (uint32_t)n;   // (n >= 8 here)
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     for (;;) {
                         const uint32_t rnd = ro_mix32(a.seed ^ ro_mix32((uint32_t)h * 0x9E3779B9u + 0x85EBCA6Bu * draw));
                         draw++;
-                        const int cand = (int)(rnd % (uint32_t)n);
+                        // rnd % n by the reciprocal: the quotient estimate is short by two at most
+                        uint32_t rem = rnd - __umulhi(rnd, n_inv) * (uint32_t)n;
+                        rem = rem >= (uint32_t)n ? rem - (uint32_t)n : rem;
+                        rem = rem >= (uint32_t)n ? rem - (uint32_t)n : rem;
+                        const int cand = (int)rem;
                         bool dup = false;
 #pragma unroll
                         for (int q = 0; q < 8; q++) dup |= (q < k) && idx[q] == cand;
@@ -320,21 +367,30 @@ __global__ void __launch_bounds__(T) ransac_kernel(OutlierArgs a) {
                 if (t == 0) {
                     barriers++;
                     if (!ro_pair_barrier(gbar, (unsigned)parts * barriers, a.spin_limit)) s_abort = 1;
-                    for (int q = q0; q < q0 + RO_SUB; q++) cnt[q] = __hip_atomic_load(&gcnt[h0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // as a sequential loop over hypotheses would see them
-            if (t == 0) {
-                int stop = s_stop, best = s_best;
-                for (int q = q0; q < q0 + RO_SUB && h0 + q < stop; q++) {
-                    if (!valid[q] || cnt[q] <= best) continue;
-                    best = cnt[q];
-                    for (int k = 0; k < 9; k++) best_F[k] = Fs[q][k];
-                    s_have = 1;
-                    const int need = ro_hypotheses_needed(best, n, a.hypotheses);
-                    stop = need < stop ? need : stop;
+            // As a sequential loop over the hypotheses would see them, by the first wavefront: lane k holds model k's
+            // count and the number of hypotheses it would leave if it became the best (worked out side by side: that
+            // number is a function of the count alone); the walk itself then runs on registers.
+            if (t < 64) {
+                const int k_own = t & (RO_SUB - 1);
+                const int c_own = parts > 1 ? __hip_atomic_load(&gcnt[h0 + q0 + k_own], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cnt[q0 + k_own];
+                const int v_own = valid[q0 + k_own];
+                int stop = s_stop, best = s_best, win = -1;
+                const int need_own = (v_own && c_own > best) ? ro_hypotheses_needed(c_own, n, a.hypotheses) : a.hypotheses;
+#pragma unroll
+                for (int k = 0; k < RO_SUB; k++) {
+                    const int ck = __builtin_amdgcn_readlane(c_own, k), vk = __builtin_amdgcn_readlane(v_own, k), nk = __builtin_amdgcn_readlane(need_own, k);
+                    if (h0 + q0 + k < stop && vk && ck > best) {
+                        best = ck; win = k;
+                        stop = nk < stop ? nk : stop;
+                    }
                 }
-                s_stop = s_abort ? 0 : stop; s_best = best;
+                if (win >= 0 && t < 9) best_F[t] = Fs[q0 + win][t];
+                if (t == 0) {
+                    if (win >= 0) s_have = 1;
+                    s_stop = s_abort ? 0 : stop; s_best = best;
+                }
             }
             __syncthreads();
         }
