@@ -348,6 +348,46 @@ def test_pyramid_then_detector_in_shared_launches(dev, shape, max_level, n, fuse
                 assert np.array_equal(out[i, : n_out[i]], want)
 
 
+@pytest.mark.parametrize("shape,max_level,n,pad", [((480, 752), 3, 3, 0), ((479, 751), 2, 2, 5), ((720, 1280), 4, 2, 0), ((240, 376), 1, 2, 3), ((120, 188), 0, 2, 1)])
+def test_device_frames_then_detector_in_shared_launches(dev, shape, max_level, n, pad):
+    """Frames already in device memory (any stride and alignment): a detector call right behind the pyramid call carries the
+    pyramid's upper levels in its own launches.  Every level and the ranked keypoints equal the CPU checker's; a second
+    round with a flush in between, and a third where another pyramid call comes before the detector call, do as well."""
+    import torch
+    h, w = shape
+    stride = w + pad
+    frames = [synth.texture(w, h, seed=400 + i, n_shapes=300) for i in range(3 * n)]
+    flat = torch.zeros(3 * n * h * stride + 64, dtype=torch.uint8, device="cuda")
+    ptrs = []
+    for i, im in enumerate(frames):
+        padded = np.zeros((h, stride), np.uint8)
+        padded[:, :w] = im
+        off = (1 if pad else 0) + i * h * stride
+        flat[off:off + h * stride] = torch.from_numpy(padded.reshape(-1)).cuda()
+        ptrs.append(flat.data_ptr() + off)
+    torch.cuda.synchronize()
+    with _ctx(dev, w, h, n_streams=n, n_slots=3, max_per_cell=16) as ctx:
+        for rnd in range(3):
+            fr, pp = frames[rnd * n:(rnd + 1) * n], ptrs[rnd * n:(rnd + 1) * n]
+            if rnd == 2:   # the frames of round 0 again into the slots of round 0, held back and then pushed out by the next call
+                ctx.set_frames_device_pyramid(list(range(n)), [0] * n, ptrs[:n], w, h, stride, max_level, 21)
+            ach = ctx.set_frames_device_pyramid(list(range(n)), [rnd] * n, pp, w, h, stride, max_level, 21)
+            if rnd == 1:
+                ctx.flush()
+            out, n_out, _ = ctx.fast_grid(list(range(n)), [rnd] * n, 20, 5, 4, 8, sync=False)
+            ctx.sync()
+            for i, f in enumerate(fr):
+                ref = O.Pyramid(f, 21, max_level)
+                assert ach[i] == ref.levels - 1
+                for l in range(ref.levels):
+                    assert np.array_equal(ctx.download_level(i, rnd, l), ref.level(l)), f"round {rnd} image {i} level {l}"
+                want = O.grid_fast(f, 8 * 20 - 1, 5, 4, 20)
+                assert np.array_equal(out[i, : n_out[i]], want)
+            if rnd == 2:
+                for i, f in enumerate(frames[:n]):
+                    assert np.array_equal(ctx.download_level(i, 0, 0), f)
+
+
 def test_fast_grid_batched_and_plateaus(dev):
     rng = np.random.default_rng(7)
     imgs = [synth.texture(376, 240, seed=90 + i, n_shapes=300) for i in range(3)]
