@@ -371,7 +371,12 @@ void launch_reject(ft_ctx* c, OutlierArgs o, int n_jobs, const int* counts) {
         const int g = split ? parts[j] : 1;
         for (int k = 0; k < g; k++) o.wg_map[wgs++] = (uint32_t)j | ((uint32_t)k << 16) | ((uint32_t)g << 24);
     }
-    if (!split && max_points > 1024) hipLaunchKernelGGL(ransac_kernel<512>, dim3(wgs), dim3(512), 0, enq(c), o);   // 512: the most that leaves the hypothesis phase its 193 registers
+    // a split launch of up to 64 parts also takes 512 threads per part: the per-point phases of a part of 512 points are
+    // half as long (cfg3 21.1 -> 19.0 us, cfg5 23.5 -> 21.8 us), and that many parts are resident beside a second launch
+    // like it (FT_RO_SPLIT_THREADS=256: the narrow form)
+    static const int split_threads = getenv("FT_RO_SPLIT_THREADS") ? atoi(getenv("FT_RO_SPLIT_THREADS")) : 512;
+    const bool wide = (!split && max_points > 1024) || (split && split_threads == 512 && wgs <= 64);
+    if (wide) hipLaunchKernelGGL(ransac_kernel<512>, dim3(wgs), dim3(512), 0, enq(c), o);   // 512: the most that leaves the hypothesis phase its 193 registers
     else hipLaunchKernelGGL(ransac_kernel<256>, dim3(wgs), dim3(256), 0, enq(c), o);
     prof_end(c, ep);
     if (!(c->profile & 1) && c->use_done_flag) c->tail_flag_seq = seq;   // (with timing on, an event record follows the launch)
