@@ -94,9 +94,13 @@ void TrackKLT::mono_begin(double timestamp, int cols, int rows, size_t cam_id, M
     for (StereoDet& D : stereo_cache)   // a stereo-path detection of this camera's stream does not survive monocular feeds
         if (D.stream == stream0 + (int)cam_id) D.valid = false;
     CamState& cs = cams[cam_id];
-    // reset the plan but keep the capacity of its arrays
+    // reset the plan.  The tracking arrays keep their contents as well as their capacity: mono_prepare sets their sizes and
+    // every element below those sizes is written before it is read (by this thread or by the delivery of the device's
+    // results), while clearing them first made each resize fill a large stream's arrays with zeros again.  The database
+    // arrays are cleared: they come back from a writer thread's core, and the zero fill of the resize that follows takes
+    // their lines over in one streaming pass instead of one miss per line in mono_finish (10 000 points: 22 against 87 us)
     plan.first = plan.run_lk = plan.reset = plan.use_H = plan.db_pending = false;
-    plan.prev_xy.clear(); plan.next_xy.clear(); plan.err.clear(); plan.status.clear(); plan.db_ids.clear(); plan.db_uvn.clear();
+    plan.db_ids.clear(); plan.db_uvn.clear();
     plan.cam = cam_id;
     frames_fed++;
     drop_tracks(pts_last[cam_id], ids_last[cam_id]);
