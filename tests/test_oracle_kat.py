@@ -390,3 +390,43 @@ def test_match_descriptors_ratio_symmetry_and_degenerate_sets():
     near = base[3].copy(); near[5] ^= 0x0f
     m = O.match_descriptors(np.stack([near, base[3]]), np.stack([base[3], base[0]]), knn_ratio=0.7)
     assert [tuple(r) for r in m] == [(1, 0, 0)]
+
+
+def test_adaptive_hypothesis_count_shortcut_equals_the_walk(tmp_path):
+    """The device decides the adaptive hypothesis count of the outlier rejection by repeated squaring wherever that cannot
+    differ from the definition (the smallest N whose running product q * q * ... * q, N factors in that order, is <= 0.001)
+    and walks the products only in a narrow band.  The function is host-compilable text: it is cut out of the kernel
+    header, built with g++ (the fast logarithm replaced by logf: it only places the first guess) and compared with the
+    plain walk for every (inliers, points) pair up to 400 points, a sample of larger sets, and several limits."""
+    import ctypes, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "feature_tracker_amd", "csrc", "ft_kernels_outlier.hpp")).read()
+    a = src.index("__device__ inline double ro_pow_int")
+    b = src.index("// T threads per workgroup")
+    body = src[a:b].replace("__device__ inline", "static inline").replace("__logf", "logf")
+    cpp = tmp_path / "count.cpp"
+    cpp.write_text("#include <cmath>\n" + body + "\nextern \"C\" int count(int inliers, int n, int max_h) { return ro_hypotheses_needed(inliers, n, max_h); }\n")
+    so = tmp_path / "count.so"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    fn = ctypes.CDLL(str(so)).count
+    fn.argtypes = [ctypes.c_int] * 3
+    fn.restype = ctypes.c_int
+
+    def walk(inliers, n, max_h):
+        w = inliers / n
+        w2 = w * w; w4 = w2 * w2; w8 = w4 * w4
+        q = 1.0 - w8
+        p, N = 1.0, 0
+        while N < max_h:
+            p = p * q
+            N += 1
+            if p <= 0.001:
+                break
+        return N
+
+    rng = np.random.default_rng(5)
+    cases = [(i, n, m) for m in (1, 2, 32, 256, 1000, 1024) for n in range(8, 401, 7) for i in range(1, n + 1)]
+    for _ in range(20000):
+        n = int(rng.integers(400, 20000)); cases.append((int(rng.integers(1, n + 1)), n, int(rng.choice([256, 1000, 1024]))))
+    for i, n, m in cases:
+        assert fn(i, n, m) == walk(i, n, m), (i, n, m)
