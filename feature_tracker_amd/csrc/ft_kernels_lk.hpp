@@ -737,8 +737,15 @@ __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEG
     // ---- Newton iterations on the target image, fed from LDS ----
     float pdx = 0.f, pdy = 0.f;
     n_iter = 0;
+    // What a lane keeps across Newton iterations that stay within one pixel: with 4-pixel segments the pixel pairs of its
+    // two rows (8 registers, and 16 unpacking instructions less per such iteration: 15 x 15 on 9 531 features 67.4 -> 65.9 us);
+    // with longer segments only the realigned rows: the pairs of 8-pixel segments (16 registers) take the kernel from 112
+    // to 122 registers, which makes it 2 % faster alone (79.9 -> 78.1 us) and the 64-stream pipeline 1 % slower, because
+    // the other queues' kernels then find no registers left beside four tracking wavefronts on a SIMD
+    constexpr bool HOLD_PAIRS = SEGLEN <= 4;
     uint32_t e0[SEGLEN / 4 + 1], e1[SEGLEN / 4 + 1];
-    int held_x = INT_MIN, held_y = INT_MIN;    // integer position whose rows e0, e1 hold
+    uint32_t p0[SEGLEN], p1[SEGLEN];           // (J[k], J[k+1]) pairs of the lane's two rows
+    int held_x = INT_MIN, held_y = INT_MIN;    // integer position whose rows are held
     for (int j = 0; j < a.max_iter; j++) {
         const int inx = lk_uniform_floor(nx), iny = lk_uniform_floor(ny);
         if (inx < -ww || inx >= w || iny < -wh || iny >= h) {
@@ -752,16 +759,21 @@ __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEG
         }
         const BilinW jw = bilin_weights(nx - inx, ny - iny);
         const uint32_t wtop = (uint32_t)jw.w00 | ((uint32_t)jw.w01 << 16), wbot = (uint32_t)jw.w10 | ((uint32_t)jw.w11 << 16);
-        // most steps after the first stay within one pixel: the realigned rows are then those of the last iteration
+        // most steps after the first stay within one pixel: the rows are then those of the last iteration
         if (inx != held_x || iny != held_y) {
             const int boff = inx - R.rx0 + x0, row = iny - R.ry0 + rc;
             read_row_aligned<SEGLEN, LK_PITCH>(jlds, row, boff, e0);
             read_row_aligned<SEGLEN, LK_PITCH>(jlds, row + 1, boff, e1);
+            if (HOLD_PAIRS) {
+                unpack_row_pairs<SEGLEN>(e0, p0);
+                unpack_row_pairs<SEGLEN>(e1, p1);
+            }
             held_x = inx; held_y = iny;
         }
-        uint32_t p0[SEGLEN], p1[SEGLEN];
-        unpack_row_pairs<SEGLEN>(e0, p0);
-        unpack_row_pairs<SEGLEN>(e1, p1);
+        if (!HOLD_PAIRS) {
+            unpack_row_pairs<SEGLEN>(e0, p0);
+            unpack_row_pairs<SEGLEN>(e1, p1);
+        }
         int b1 = 0, b2 = 0;
 #pragma unroll
         for (int m = 0; m < SEGLEN / 2; m++) {
