@@ -417,8 +417,10 @@ static int run_levels(ft_ctx* c, const ImgList& L, int w, int h, int top, bool d
         const int do_grad = grad ? 1 : 0;
         if (l >= from_level && (do_down || do_grad)) {
             const int tiles = ((lw + LV_TX - 1) / LV_TX) * ((lh + LV_TY - 1) / LV_TY);
-            hipLaunchKernelGGL((level_kernel<false>), dim3(xcd_grid(tiles * L.n)), dim3(256), 0, enq(c), c->arena, L, none, 0, l, lw, lh,
-                               (uint64_t)0, do_grad, do_down);
+            if (do_grad) hipLaunchKernelGGL((level_kernel<false, true>), dim3(xcd_grid(tiles * L.n)), dim3(256), 0, enq(c), c->arena, L, none, 0, l, lw, lh,
+                                            (uint64_t)0, do_grad, do_down);
+            else hipLaunchKernelGGL((level_kernel<false, false>), dim3(xcd_grid(tiles * L.n)), dim3(256), 0, enq(c), c->arena, L, none, 0, l, lw, lh,
+                                    (uint64_t)0, 0, do_down);
         }
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
     }
@@ -787,7 +789,7 @@ static int frames_to_pyramid(ft_ctx* c, const ImgList& L, int n, const uint8_t* 
         const int m = std::min(FRAME_PTRS, n - first);
         FramePtrs F{};
         for (int i = 0; i < m; i++) F.p[i] = src[first + i];
-        hipLaunchKernelGGL((level_kernel<true>), dim3(xcd_grid(tiles * m)), dim3(256), 0, enq(c), c->arena, L, F, first, 0, w, h,
+        hipLaunchKernelGGL((level_kernel<true, false>), dim3(xcd_grid(tiles * m)), dim3(256), 0, enq(c), c->arena, L, F, first, 0, w, h,
                            (uint64_t)stride, 0, top > 0 ? 1 : 0);
     }
     FT_HIP(c, hipGetLastError());

@@ -189,7 +189,11 @@ __device__ __forceinline__ void level_tile(const ArenaDesc& A, const ImgList& L,
     }
 }
 
-template <bool FROM_FRAME>
+// GRAD = false: the form without gradient images, as the tracking pipeline launches it (do_grad is ignored).  It is a
+// kernel of its own for its registers: the Scharr step keeps a 6 x 6 pixel block per thread, and a kernel that only might
+// run it is allocated for it; without it a wavefront takes few enough registers for several of them to find room on a
+// SIMD that four tracking wavefronts of another queue have filled but for 64 registers.
+template <bool FROM_FRAME, bool GRAD = true>
 __global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, FramePtrs F, int first, int level, int w, int h, uint64_t sstride,
                                                     int do_grad, int do_down) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[LV_LDS_ROWS * LV_LDS_PITCH];
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(256) level_kernel(ArenaDesc A, ImgList L, Fram
     const int n_img = FROM_FRAME ? min(FRAME_PTRS, L.n - first) : L.n;
     const int item = xcd_item(blockIdx.x, tiles * n_img);
     if (item >= tiles * n_img) return;
-    level_tile<FROM_FRAME>(A, L, F, first, level, w, h, sstride, do_grad, do_down, item, threadIdx.x, tile);
+    level_tile<FROM_FRAME>(A, L, F, first, level, w, h, sstride, GRAD ? do_grad : 0, do_down, item, threadIdx.x, tile);
 }
 
 // ---- batched frame ingest: n device-resident frames -> level 0 of their slots, one launch ----
