@@ -24,8 +24,11 @@ KINDS = {"lk_track": ("lk_kernel", "lk_pair_kernel"), "pyramid": ("level_kernel<
 
 
 def short(name):
-    m = re.search(r"(lk_pair_kernel|lk_kernel|level_kernel<true>|level_kernel<false>|ingest_linear_kernel|ingest_kernel|fast_detect_kernel|fast_topk_kernel|ransac_kernel|fetch_block_kernel)", name)
-    return m.group(1) if m else None
+    m = re.search(r"(lk_pair_kernel|lk_kernel|level_kernel<(?:true|false)|ingest_linear_kernel|ingest_kernel|fast_detect_kernel|fast_topk_kernel|ransac_kernel|fetch_block_kernel)", name)
+    if not m:
+        return None
+    k = m.group(1)
+    return k + ">" if k.startswith("level_kernel<") else k   # level_kernel<true, false> (frame pass, no gradient images) -> level_kernel<true>
 
 
 def collect(d):
