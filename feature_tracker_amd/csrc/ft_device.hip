@@ -173,6 +173,7 @@ struct ft_ctx {
     int lk_direct_max = 1024; // points per tracking launch up to which the input block is read in place from pinned memory (FT_LK_DIRECT_MAX)
     bool lk_fixed_windows = true;   // kernels compiled for 21 x 21 and 15 x 15 windows (FT_LK_FIXED_WINDOWS=0: the general ones)
     bool lk_fused_fb = true;  // forward-backward tracking in one launch (FT_LK_FUSED_FB=0: two launches)
+    bool lk_hold_single = true;   // one-stream contexts: 21 x 21 kernels that hold their pixel pairs (FT_LK_HOLD_SINGLE=0: the usual ones)
     int lk_pair_max = 2048;   // points per tracking launch up to which lk_pair_kernel runs (FT_LK_PAIR_MAX overrides it: 0 = never)
     std::vector<EventPair> ev_inflight;
     std::vector<EventPair> ev_pool;
@@ -461,12 +462,17 @@ template <int SEGLEN, bool FUSED, int WIN>
 static void launch_lk(ft_ctx* c, const LKArgs& a, int total) {
     // Up to one wavefront pair per wave slot pair of the device the two-wave form is the faster one (its chain of
     // dependent steps is a third shorter); beyond that the idle halves of the pairs cost more than the chain saves.
+    // a context of one stream has the device to itself while it tracks: its 21 x 21 launches take the kernels that keep
+    // their pixel pairs across iterations (122 registers instead of 112: nothing else wants the difference there)
+    const bool hold = WIN == 21 && SEGLEN == 8 && c->lk_hold_single && c->lim.n_streams == 1 && a.win_h <= 21;
     if (total <= c->lk_pair_max) {
         if (a.win_h > 21) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, true, FUSED, 0>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
+        else if (hold) hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false, FUSED, WIN, WIN == 21 && SEGLEN == 8>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
         else hipLaunchKernelGGL((lk_pair_kernel<SEGLEN, false, FUSED, WIN>), dim3(xcd_grid(total)), dim3(128), 0, enq(c), a);
         return;
     }
     if (a.win_h > 21) hipLaunchKernelGGL((lk_kernel<SEGLEN, true, FUSED, 0>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
+    else if (hold) hipLaunchKernelGGL((lk_kernel<SEGLEN, false, FUSED, WIN, WIN == 21 && SEGLEN == 8>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
     else hipLaunchKernelGGL((lk_kernel<SEGLEN, false, FUSED, WIN>), dim3(xcd_grid(total)), dim3(64), 0, enq(c), a);
 }
 // the windows with kernels of their own: 21 x 21 (8-pixel segments) and the reference's 15 x 15 (4-pixel segments)
@@ -526,6 +532,7 @@ int ft_ctx_create(ft_ctx** out, int device, const ft_limits* lim) {
     c->lim = *lim;
     if (const char* e = getenv("FT_LK_PAIR_MAX")) c->lk_pair_max = atoi(e);
     if (const char* e = getenv("FT_LK_DIRECT_MAX")) c->lk_direct_max = atoi(e);
+    if (const char* e = getenv("FT_LK_HOLD_SINGLE")) c->lk_hold_single = atoi(e) != 0;
     if (const char* e = getenv("FT_FRONT_FUSE")) c->front_fuse = atoi(e) != 0;
     if (const char* e = getenv("FT_LK_FIXED_WINDOWS")) c->lk_fixed_windows = atoi(e) != 0;
     if (const char* e = getenv("FT_LK_FUSED_FB")) c->lk_fused_fb = atoi(e) != 0;

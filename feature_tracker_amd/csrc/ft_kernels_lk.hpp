@@ -722,7 +722,7 @@ __device__ __forceinline__ int lk_matrix_test(const LKArgs& a, const LkWave<SEGL
 
 // Newton iterations of one level on the staged J region R (re-staged when the window walks out of it), the per-level
 // iteration count, and at level 0 the residual at the final position.
-template <int SEGLEN, bool TALL>
+template <int SEGLEN, bool TALL, bool HOLD = false>
 __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEGLEN>& W, int bwd, int pt, int level, uint32_t* __restrict__ jlds,
                                                const uint8_t* __restrict__ imgJ, uint32_t ipitch, int w, int h, const int (&Cw)[SEGLEN],
                                                const uint32_t (&GX)[SEGLEN / 2], const uint32_t (&GY)[SEGLEN / 2], float A11, float A12, float A22,
@@ -741,8 +741,9 @@ __device__ __forceinline__ void lk_track_level(const LKArgs& a, const LkWave<SEG
     // two rows (8 registers, and 16 unpacking instructions less per such iteration: 15 x 15 on 9 531 features 67.4 -> 65.9 us);
     // with longer segments only the realigned rows: the pairs of 8-pixel segments (16 registers) take the kernel from 112
     // to 122 registers, which makes it 2 % faster alone (79.9 -> 78.1 us) and the 64-stream pipeline 1 % slower, because
-    // the other queues' kernels then find no registers left beside four tracking wavefronts on a SIMD
-    constexpr bool HOLD_PAIRS = SEGLEN <= 4;
+    // the other queues' kernels then find no registers left beside four tracking wavefronts on a SIMD.  HOLD: the form
+    // with the pairs held all the same, for a context whose tracking launches have the device to themselves (one stream)
+    constexpr bool HOLD_PAIRS = SEGLEN <= 4 || HOLD;
     uint32_t e0[SEGLEN / 4 + 1], e1[SEGLEN / 4 + 1];
     uint32_t p0[SEGLEN], p1[SEGLEN];           // (J[k], J[k+1]) pairs of the lane's two rows
     int held_x = INT_MIN, held_y = INT_MIN;    // integer position whose rows are held
@@ -877,7 +878,7 @@ __device__ __forceinline__ void lk_write_fused(const LKArgs& a, int pt, const Lk
 // All levels of one feature on one wavefront.  SEGLEN: pixels per lane segment; TALL: window height above 21 rows (more
 // staged rows per lane); FUSED: forward pass, then the backward pass of the same feature (launched with a.backward = 0).
 // jlds / ilds: the wavefront's LDS arrays for the target and the template region.
-template <int SEGLEN, bool TALL, bool FUSED, int WIN>
+template <int SEGLEN, bool TALL, bool FUSED, int WIN, bool HOLD = false>
 __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, uint32_t* __restrict__ jlds, uint32_t* __restrict__ ilds, float* __restrict__ fwd) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
@@ -939,7 +940,7 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
             if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             continue;
         }
-        lk_track_level<SEGLEN, TALL>(a, W, bwd, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
+        lk_track_level<SEGLEN, TALL, HOLD>(a, W, bwd, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
         __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
     }
     if (!FUSED) {
@@ -966,7 +967,7 @@ __device__ __forceinline__ void lk_one_point(const LKArgs& a, int pt, int lane, 
 // atomics per counter, performed memory-side, cost more than the dispatches they replace), features dealt to the
 // resident wavefronts in fixed strides 88 us (no counters, but no balancing either).  Wavefronts that stay warm gain
 // nothing: the launch is bound by vector issue between its ends, and its ends by one wavefront's dependent chain.
-template <int SEGLEN, bool TALL, bool FUSED, int WIN>
+template <int SEGLEN, bool TALL, bool FUSED, int WIN, bool HOLD = false>
 __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;
@@ -977,7 +978,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
     const int pt = xcd_item(blockIdx.x, a.total);   // points of one image pair stay on one XCD
     if (pt >= a.total) return;
     __shared__ float fwd[3];                                     // FUSED: the forward result during the backward pass
-    lk_one_point<SEGLEN, TALL, FUSED, WIN>(a, pt, threadIdx.x, jlds, ilds, fwd);
+    lk_one_point<SEGLEN, TALL, FUSED, WIN, HOLD>(a, pt, threadIdx.x, jlds, ilds, fwd);
 }
 
 // The same tracking with two wavefronts per feature.  The template of a level (staging of the I region, Scharr patch,
@@ -990,7 +991,7 @@ __global__ void __launch_bounds__(64) lk_kernel(LKArgs a) {
 // a third shorter; the arithmetic, and so every result, is that of lk_kernel.  FUSED: after the forward pass the
 // tracker hands its result to the templater through LDS (one more barrier for both) and both go through the levels
 // again for the backward pass.
-template <int SEGLEN, bool TALL, bool FUSED, int WIN>
+template <int SEGLEN, bool TALL, bool FUSED, int WIN, bool HOLD = false>
 __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
     constexpr int WH_MAX = TALL ? 32 : 21;
     constexpr int I_ROWS = (WH_MAX + 3 + 3) / 4;                    // staged rows per lane, template region
@@ -1079,7 +1080,7 @@ __global__ void __launch_bounds__(128) lk_pair_kernel(LKArgs a) {
                 if (level == 0) st = 0;
                 if (a.iters && !bwd && lane == 0) a.iters[(size_t)pt * a.nlev + level] = -1;
             } else {
-                lk_track_level<SEGLEN, TALL>(a, W, bwd, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
+                lk_track_level<SEGLEN, TALL, HOLD>(a, W, bwd, pt, level, jlds, G.imgJ, G.ipitch, w, h, Cw, GX, GY, A11, A12, A22, R, G.nx, G.ny, outx, outy, st, errv);
                 __builtin_amdgcn_wave_barrier();   // all LDS reads of this level precede the next level's staging
             }
         }

@@ -172,6 +172,23 @@ def test_lk_matches_oracle(dev, win, max_level, shape, n, lk_form, monkeypatch):
         monkeypatch.delenv("FT_LK_FIXED_WINDOWS")
         for a, b in zip(out, gen):
             assert np.array_equal(a, b)
+    if win == 21:
+        # a context of one stream takes the 21 x 21 kernels that hold their pixel pairs across iterations (FT_LK_HOLD_SINGLE=0: not)
+        with _ctx(dev, w, h, n_streams=1) as ctx:
+            ctx.upload(0, 0, prev)
+            ctx.upload(0, 1, nxt)
+            ctx.build_pyramid([0, 0], [0, 1], max_level, win, with_gradients=False)
+            one = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=max_level), want_iters=True)[0]
+            fb = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=max_level, flags=dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_FORWARD_BACKWARD, fb_thresh=1.0))[0]
+        for a, b in zip(out, one):
+            assert np.array_equal(a, b)
+        with _ctx(dev, w, h) as ctx:
+            ctx.upload(0, 0, prev)
+            ctx.upload(0, 1, nxt)
+            ctx.build_pyramid([0, 0], [0, 1], max_level, win, with_gradients=False)
+            fb2 = ctx.lk_track([dict(prev=(0, 0), next=(0, 1), prev_xy=pts)], dev.LKParams(win=win, max_level=max_level, flags=dev.FT_LK_USE_INITIAL_FLOW | dev.FT_LK_FORWARD_BACKWARD, fb_thresh=1.0))[0]
+        for a, b in zip(fb, fb2):
+            assert np.array_equal(a, b)
 
 
 def test_lk_initial_guess_no_initial_flow_and_min_eig(dev, lk_form):
